@@ -1,0 +1,38 @@
+# Entry points keep the reference's names (Makefile:1-4 there: `all` builds the host objects
+# and the rpv2 binary); everything is built for gfx950 only.
+#
+#   make / make all   libwrp.so (C ABI + HIP kernels), host objects, rpv2 binary, oracle
+#   make lib          weather-radar-processing_amd/lib/libwrp.so only
+#   make oracle       oracle/liboracle.so (+ oracle/_ref when /root/reference exists)
+#   make clean
+
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+PKG      := weather-radar-processing_amd
+CSRC     := $(PKG)/csrc
+HOST     := $(PKG)/host
+LIBDIR   := $(PKG)/lib
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=fast
+CXXFLAGS ?= -O2 -std=c++17 -fPIC -Wall
+
+all: lib host oracle
+
+lib: $(LIBDIR)/libwrp.so
+
+$(LIBDIR)/libwrp.so: $(CSRC)/wrp_engine.hip $(CSRC)/wrp_kernels.h $(CSRC)/fft_radix.h include/wrp.h
+	mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/wrp_engine.hip
+
+host:
+	@if [ -f $(HOST)/Makefile ]; then $(MAKE) -C $(HOST); fi
+
+oracle:
+	$(MAKE) -C oracle
+	@if [ -d /root/reference ]; then $(MAKE) -C oracle ref; fi
+
+clean:
+	rm -rf $(LIBDIR)
+	$(MAKE) -C oracle clean
+	@if [ -f $(HOST)/Makefile ]; then $(MAKE) -C $(HOST) clean; fi
+
+.PHONY: all lib host oracle clean

@@ -1,0 +1,145 @@
+/*
+ * wrp.h -- C ABI of the MI355X per-sector weather-radar DSP engine (libwrp.so).
+ *
+ * The reference (rsatrioadi/weather-radar-processing) has no FFI: every GPU
+ * variant is one main() with its kernels inline.  The seam this ABI replaces is
+ * the stage-function set of rpv2.cu (same names as RadarProcessor's private
+ * methods, radar_processor.h:63-84):
+ *
+ *   generate_constants + prepare_arys + initialize_streams   rpv2.cu:283-341  -> wrp_create
+ *   p_iq pinned staging, Dimension4(n, m, 3, streams)        rpv2.cu:289-293  -> wrp_pinned_slot
+ *   copy_matrix_to_device                                    rpv2.cu:399-407  \
+ *   perform_stage_1 / _2 / _3                                rpv2.cu:409-570   > wrp_submit
+ *   copy_result_to_host                                      rpv2.cu:581-618  /
+ *   result[sitdim(2, m/2, sectors, elevations)]              rpv2.cu:620-630  -> wrp_wait + wrp_result
+ *   commented stage dumps                                    rpv2.cu:582-603  -> wrp_dump_stage
+ *   destroy_streams + destroy_arrays                         rpv2.cu:685-722  -> wrp_destroy
+ *
+ * Plain C types only; no HIP or torch types cross the boundary (a stream is
+ * passed as void* = hipStream_t, NULL = the engine's own stream).
+ *
+ * Ownership: the handle owns all device and pinned memory.  The caller writes
+ * only into a pinned slot, and only between wrp_wait(slot) (or creation) and
+ * the next wrp_submit(slot).
+ * Errors: the reference exits the process (gpuErrchk, rpv2.cu:21-27); this ABI
+ * returns 0 or a negative wrp_status and never throws or exits.
+ * Threading: one handle per GPU; a handle is not thread-safe; distinct handles
+ * may be driven from distinct threads (one feeder thread per GPU).
+ */
+#ifndef WRP_H
+#define WRP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wrp_engine *wrp_handle;
+
+typedef enum {
+    WRP_OK = 0,
+    WRP_ERR_INVALID = -1,     /* bad argument */
+    WRP_ERR_HIP = -2,         /* a HIP runtime call failed (see wrp_last_hip_error) */
+    WRP_ERR_NOMEM = -3,
+    WRP_ERR_UNSUPPORTED = -4, /* shape has no kernel instantiation */
+    WRP_ERR_STATE = -5        /* call order violated (e.g. wait on an idle slot) */
+} wrp_status;
+
+/* Mirrors the compile-time constants of rpv2.cu:38-45 as run-time values. */
+typedef struct {
+    int m;            /* range cells per sector  = range-FFT length   (n_sweeps, 1024) */
+    int n;            /* pulses per range cell   = Doppler-FFT length (n_samples, 512) */
+    int channels;     /* planes per IQ block: 2 = HH,VV; 3 = HH,VV,VH (Dimension4 copies).
+                         VH is carried but never read -- no output depends on it
+                         (rpv2.cu:199-213 ignores offset_vh). */
+    int n_slots;      /* stream slots = Dimension4 depth (rpv2.cu:728-734 num_streams) */
+    int n_sectors;    /* sectors per elevation in the host result table (143) */
+    int n_elevations; /* elevations in the host result table (9) */
+    int ma_count;     /* moving-average taps (7), 1..9 */
+    float k_range_resolution; /* 30    (rpv2.cu:43) */
+    float k_calibration;      /* 1941.05 (rpv2.cu:44) */
+    int max_batch;    /* sectors processed per internal chunk of wrp_process_batch_device;
+                         sizes the device workspace (0 = default) */
+    int flags;        /* reserved, must be 0 */
+} wrp_config;
+
+/* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
+typedef enum {
+    WRP_STAGE_01HAMM = 1,         /* m x n complex  after the Hamming window          (a2) */
+    WRP_STAGE_02FFT1 = 2,         /* m x n complex  after the range FFT               (a3) */
+    WRP_STAGE_03FFT2_NOSHIFT = 3, /* m/2 x n complex Doppler FFT before conj/shift/clip    */
+    WRP_STAGE_03FFT2 = 4,         /* m/2 x n complex after conj + shift + clip        (a5) */
+    WRP_STAGE_04ABS = 5,          /* m/2 x n real   |.|^2                             (a6) */
+    WRP_STAGE_08POW = 6,          /* m/2 x n real   MA-smoothed power                 (a7) */
+    WRP_STAGE_ROWSUM = 7          /* m/2 real       S[i]                              (a8) */
+} wrp_stage;
+
+/* Fill *cfg with the reference's constants (m=1024, n=512, channels=2, 2 slots,
+ * 143 sectors, 9 elevations, 7 taps, 30, 1941.05). */
+void wrp_default_config(wrp_config *cfg);
+
+/* generate_constants + prepare_arys + initialize_streams (rpv2.cu:283-341):
+ * window / twiddle / MA tables, per-slot device buffers, pinned staging, streams. */
+int wrp_create(const wrp_config *cfg, int device, wrp_handle *out);
+
+/* destroy_streams + destroy_arrays (rpv2.cu:685-722). NULL is a no-op. */
+void wrp_destroy(wrp_handle h);
+
+const char *wrp_strerror(int status);
+/* Text of the last failing HIP call on this handle ("" if none). */
+const char *wrp_last_hip_error(wrp_handle h);
+
+/* p_iq of rpv2.cu:291: pinned, caller-fillable staging buffer of one slot, laid out
+ * as Dimension4(n, m, channels, slots) at depth = slot, i.e.
+ * [channel][row i < m][col j < n] interleaved complex fp32.  *bytes = channels*m*n*8. */
+int wrp_pinned_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes);
+
+/* copy_matrix_to_device + perform_stage_1..3 + copy_result_to_host (rpv2.cu:399-618),
+ * asynchronous on the slot's stream: H2D of the pinned slot, the fused chain, D2H of
+ * [m/2][2] floats into the host result table at (elevation, sector). */
+int wrp_submit(wrp_handle h, int slot, int sector, int elevation);
+
+/* Block until the slot's last wrp_submit has completed. */
+int wrp_wait(wrp_handle h, int slot);
+
+/* Pointer into the host result table result[sitdim(2, m/2, n_sectors, n_elevations)]
+ * (rpv2.cu:736, :626-629): (*zdb_zdr)[gate*2 + 0] = Zdb, [gate*2 + 1] = Zdr. */
+int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr);
+
+/* Kernel-only entries (device-resident in and out; used for roofline timing and by
+ * callers that already hold the IQ block on the GPU).
+ * d_iq : [n_sectors][channels][m][n] complex fp32;  d_out : [n_sectors][m/2][2] fp32.
+ * stream: hipStream_t as void*, NULL = the engine's compute stream.  Asynchronous. */
+int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream);
+int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream);
+
+/* Synchronous convenience: host buffers in the same layouts (pageable or pinned). */
+int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *out_host);
+
+/* Debug/parity: re-run the chain on the slot's device IQ block (as last uploaded by
+ * wrp_submit) with stage dumping enabled and copy stage `stage` of `channel`
+ * (0 = HH, 1 = VV, 2 = VH) to host_out (sizes per wrp_stage). Synchronous. */
+int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_out);
+
+/* Measurement: run `iters` back-to-back wrp_process_batch_device calls on the engine's
+ * own stream bracketed by HIP events ON THAT STREAM; *ms_total = elapsed time of all
+ * iterations; ms_range / ms_doppler (optional) = summed time of the range-pass and
+ * Doppler-pass kernels measured by per-launch event pairs in a second, separate run. */
+int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
+                          int iters, float *ms_total, float *ms_range, float *ms_doppler);
+
+/* Introspection for harnesses. */
+int wrp_get_config(wrp_handle h, wrp_config *cfg);
+size_t wrp_sector_bytes(wrp_handle h);   /* channels*m*n*8 */
+size_t wrp_result_bytes(wrp_handle h);   /* (m/2)*2*4      */
+/* Algorithmic HBM bytes per sector of the fused chain:
+ * 2*m*n*8 (HH and VV read once) + (m/2)*2*4 (result written once). */
+size_t wrp_algorithmic_bytes(wrp_handle h);
+const char *wrp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WRP_H */

@@ -1,0 +1,72 @@
+"""CPU-only checks of the drop-in boundary: libwrp.so loads, exports every symbol that
+include/wrp.h declares, and refuses bad arguments without touching a GPU."""
+import ctypes as C
+
+import pytest
+
+import wrp_amd
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    lib = wrp_amd.load_library()
+    declared = wrp_amd.header_symbols()
+    assert len(declared) >= 18
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.wrp_version().decode().startswith("wrp-amd")
+
+
+def test_default_config_is_the_reference_constants():
+    cfg = wrp_amd.binding.default_config()
+    # rpv2.cu:38-45
+    assert (cfg.m, cfg.n, cfg.n_sectors, cfg.n_elevations, cfg.ma_count) == (1024, 512, 143, 9, 7)
+    assert cfg.k_range_resolution == 30.0 and abs(cfg.k_calibration - 1941.05) < 1e-3
+    assert cfg.channels == 2 and cfg.n_slots == 2
+
+
+def test_strerror_covers_every_status():
+    lib = wrp_amd.load_library()
+    texts = {lib.wrp_strerror(s).decode() for s in (0, -1, -2, -3, -4, -5)}
+    assert len(texts) == 6 and "ok" in texts
+    assert "unknown" in lib.wrp_strerror(-99).decode()
+
+
+def test_bad_arguments_are_rejected_before_any_gpu_call():
+    lib = wrp_amd.load_library()
+    h = C.c_void_p()
+    assert lib.wrp_create(None, 0, C.byref(h)) == -1
+    for field, bad in (("m", 0), ("channels", 4), ("n_slots", 0), ("ma_count", 10), ("flags", 1),
+                       ("n_sectors", 0), ("max_batch", -1)):
+        cfg = wrp_amd.binding.default_config(**{field: bad})
+        assert lib.wrp_create(C.byref(cfg), 0, C.byref(h)) == -1, field
+        assert not h.value
+    # a shape without a kernel instantiation is reported as such, not mis-run
+    cfg = wrp_amd.binding.default_config(m=1000, n=512)
+    assert lib.wrp_create(C.byref(cfg), 0, C.byref(h)) == -4
+    # NULL handles
+    assert lib.wrp_submit(None, 0, 0, 0) == -1
+    assert lib.wrp_wait(None, 0) == -1
+    assert lib.wrp_process_batch_device(None, None, 1, None, None) == -1
+    assert lib.wrp_sector_bytes(None) == 0
+    lib.wrp_destroy(None)  # no-op
+
+
+def test_no_cpu_fallback_exists():
+    """Without a GPU the engine must fail loudly, never compute on the host."""
+    import os
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU box")
+    with pytest.raises(wrp_amd.WrpError):
+        wrp_amd.Engine(device=0)
+
+
+def test_product_does_not_import_the_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "weather-radar-processing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".c", ".cc")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"(from|import)\s+oracle|oracle/|liboracle|wro_", text), (dirpath, f)

@@ -1,0 +1,201 @@
+"""ctypes binding of include/wrp.h (libwrp.so).  No compute happens in Python."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+_LIB = None
+
+
+class WrpError(RuntimeError):
+    def __init__(self, status, what="", detail=""):
+        self.status = status
+        super().__init__(f"wrp: {what} failed with status {status}" + (f" ({detail})" if detail else ""))
+
+
+class WrpConfig(C.Structure):
+    """wrp_config of include/wrp.h (run-time form of rpv2.cu:38-45)."""
+    _fields_ = [
+        ("m", C.c_int), ("n", C.c_int), ("channels", C.c_int), ("n_slots", C.c_int),
+        ("n_sectors", C.c_int), ("n_elevations", C.c_int), ("ma_count", C.c_int),
+        ("k_range_resolution", C.c_float), ("k_calibration", C.c_float),
+        ("max_batch", C.c_int), ("flags", C.c_int),
+    ]
+
+
+STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7}
+
+
+def STAGE_SHAPES(m, n):
+    return {
+        "01hamm": ((m, n), np.complex64), "02fft1": ((m, n), np.complex64),
+        "03fft2-noshift": ((m // 2, n), np.complex64), "03fft2": ((m // 2, n), np.complex64),
+        "04abs": ((m // 2, n), np.float32), "08pow": ((m // 2, n), np.float32),
+        "rowsum": ((m // 2,), np.float32),
+    }
+
+
+def lib_path():
+    return os.path.join(_PKG, "lib", "libwrp.so")
+
+
+def header_symbols():
+    """Every function include/wrp.h declares."""
+    text = open(os.path.join(_ROOT, "include", "wrp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wrp_[a-z_0-9]+)\s*\(", text)))
+
+
+def exported_symbols():
+    lib = load_library()
+    return [s for s in header_symbols() if hasattr(lib, s)]
+
+
+def load_library():
+    """dlopen libwrp.so; raise loudly when it is missing (no fallback path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise WrpError(-2, "load_library", f"{p} not built -- run `make lib` / __graft_entry__.build()")
+    lib = C.CDLL(p)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    fp = C.POINTER(C.c_float)
+    lib.wrp_default_config.argtypes = [C.POINTER(WrpConfig)]
+    lib.wrp_default_config.restype = None
+    lib.wrp_create.argtypes = [C.POINTER(WrpConfig), i, C.POINTER(vp)]
+    lib.wrp_destroy.argtypes = [vp]
+    lib.wrp_destroy.restype = None
+    lib.wrp_strerror.argtypes = [i]
+    lib.wrp_strerror.restype = C.c_char_p
+    lib.wrp_last_hip_error.argtypes = [vp]
+    lib.wrp_last_hip_error.restype = C.c_char_p
+    lib.wrp_pinned_slot.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.wrp_submit.argtypes = [vp, i, i, i]
+    lib.wrp_wait.argtypes = [vp, i]
+    lib.wrp_result.argtypes = [vp, i, i, C.POINTER(fp)]
+    lib.wrp_process_device.argtypes = [vp, vp, vp, vp]
+    lib.wrp_process_batch_device.argtypes = [vp, vp, i, vp, vp]
+    lib.wrp_process_host.argtypes = [vp, vp, i, vp]
+    lib.wrp_dump_stage.argtypes = [vp, i, i, i, vp]
+    lib.wrp_time_batch_device.argtypes = [vp, vp, i, vp, i, fp, fp, fp]
+    lib.wrp_get_config.argtypes = [vp, C.POINTER(WrpConfig)]
+    for name in ("wrp_sector_bytes", "wrp_result_bytes", "wrp_algorithmic_bytes"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = C.c_size_t
+    lib.wrp_version.restype = C.c_char_p
+    _LIB = lib
+    return lib
+
+
+def default_config(**over):
+    cfg = WrpConfig()
+    load_library().wrp_default_config(C.byref(cfg))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Engine:
+    """One handle per GPU -- thin object wrapper over wrp_create .. wrp_destroy."""
+
+    def __init__(self, device=0, **cfg):
+        self.lib = load_library()
+        self.cfg = default_config(**cfg)
+        self._h = C.c_void_p()
+        rc = self.lib.wrp_create(C.byref(self.cfg), device, C.byref(self._h))
+        if rc != 0:
+            raise WrpError(rc, "wrp_create", self.lib.wrp_strerror(rc).decode())
+        self.m, self.n, self.channels = self.cfg.m, self.cfg.n, self.cfg.channels
+        self.gates = self.m // 2
+
+    # -- plumbing ----------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise WrpError(rc, what, self.lib.wrp_strerror(rc).decode() + ": " +
+                           self.lib.wrp_last_hip_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.wrp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def sector_bytes(self):
+        return self.lib.wrp_sector_bytes(self._h)
+
+    @property
+    def algorithmic_bytes(self):
+        return self.lib.wrp_algorithmic_bytes(self._h)
+
+    # -- streaming seam (rpv2.cu do_process) --------------------------------------------
+    def slot_array(self, slot):
+        """numpy view [channels][m][n] complex64 of the slot's pinned staging buffer."""
+        p, nbytes = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.wrp_pinned_slot(self._h, slot, C.byref(p), C.byref(nbytes)), "wrp_pinned_slot")
+        buf = (C.c_char * nbytes.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.complex64).reshape(self.channels, self.m, self.n)
+
+    def submit(self, slot, sector, elevation=0):
+        self._check(self.lib.wrp_submit(self._h, slot, sector, elevation), "wrp_submit")
+
+    def wait(self, slot):
+        self._check(self.lib.wrp_wait(self._h, slot), "wrp_wait")
+
+    def result(self, sector, elevation=0):
+        p = C.POINTER(C.c_float)()
+        self._check(self.lib.wrp_result(self._h, sector, elevation, C.byref(p)), "wrp_result")
+        return np.ctypeslib.as_array(p, shape=(self.gates, 2))
+
+    def dump_stage(self, slot, stage, channel=0):
+        shape, dt = STAGE_SHAPES(self.m, self.n)[stage]
+        out = np.empty(shape, dt)
+        self._check(self.lib.wrp_dump_stage(self._h, slot, STAGE_IDS[stage], channel,
+                                            out.ctypes.data_as(C.c_void_p)), "wrp_dump_stage")
+        return out
+
+    # -- batch / kernel-only entries ---------------------------------------------------------
+    def process_host(self, iq):
+        """iq: [S][channels][m][n] complex64 on the host -> [S][m/2][2] float32."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        if iq.ndim == 3:
+            iq = iq[None]
+        assert iq.shape[1:] == (self.channels, self.m, self.n), iq.shape
+        out = np.empty((iq.shape[0], self.gates, 2), np.float32)
+        self._check(self.lib.wrp_process_host(self._h, iq.ctypes.data_as(C.c_void_p), iq.shape[0],
+                                              out.ctypes.data_as(C.c_void_p)), "wrp_process_host")
+        return out
+
+    def process_batch_device(self, d_iq_ptr, n_sectors, d_out_ptr, stream=None):
+        self._check(self.lib.wrp_process_batch_device(self._h, C.c_void_p(d_iq_ptr), n_sectors,
+                                                      C.c_void_p(d_out_ptr), C.c_void_p(stream or 0)),
+                    "wrp_process_batch_device")
+
+    def time_batch_device(self, d_iq_ptr, n_sectors, d_out_ptr, iters, per_kernel=False):
+        """HIP-event timing on the engine's own stream -> (ms_total, ms_range, ms_doppler)."""
+        t = C.c_float()
+        a, b = C.c_float(), C.c_float()
+        self._check(self.lib.wrp_time_batch_device(
+            self._h, C.c_void_p(d_iq_ptr), n_sectors, C.c_void_p(d_out_ptr), iters, C.byref(t),
+            C.byref(a) if per_kernel else None, C.byref(b) if per_kernel else None), "wrp_time_batch_device")
+        return t.value, (a.value if per_kernel else None), (b.value if per_kernel else None)

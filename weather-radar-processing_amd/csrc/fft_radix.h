@@ -1,0 +1,119 @@
+// fft_radix.h -- in-register radix-2/4/8/16 butterflies for gfx950 (wave64).
+//
+// Each function transforms R complex values held in one lane's VGPRs, natural
+// order in, natural order out:  X[k] = sum_r x[r] * exp(SIGN * 2*pi*i * r*k / R).
+// SIGN = -1 is the reference's FFTW_FORWARD / CUFFT_FORWARD (rpv2.cu:426),
+// SIGN = +1 the conjugate transform that conj -> FFT -> conj amounts to
+// (rpv2.cu:439,464,471).  All twiddles inside a butterfly are compile-time
+// constants; the compiler folds them into v_fma/v_mul literals.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wrp {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * w
+__device__ __forceinline__ cf cmul(cf a, cf w)
+{
+    return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y));
+}
+// a * (SIGN * i)
+template <int SIGN>
+__device__ __forceinline__ cf mul_si(cf a)
+{
+    return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+// a * exp(SIGN * i*pi/4) = a * (1 + SIGN*i)/sqrt2
+template <int SIGN>
+__device__ __forceinline__ cf mul_w8_1(cf a)
+{
+    constexpr float h = 0.70710678118654752440f;
+    return SIGN > 0 ? make_float2((a.x - a.y) * h, (a.x + a.y) * h)
+                    : make_float2((a.x + a.y) * h, (a.y - a.x) * h);
+}
+// a * exp(SIGN * 3*i*pi/4) = a * (-1 + SIGN*i)/sqrt2
+template <int SIGN>
+__device__ __forceinline__ cf mul_w8_3(cf a)
+{
+    constexpr float h = 0.70710678118654752440f;
+    return SIGN > 0 ? make_float2(-(a.x + a.y) * h, (a.x - a.y) * h)
+                    : make_float2((a.y - a.x) * h, -(a.x + a.y) * h);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void fft2(cf &a, cf &b)
+{
+    cf t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+// 4-point: X1 = (x0 - x2) + SIGN*i*(x1 - x3)
+template <int SIGN>
+__device__ __forceinline__ void fft4(cf &x0, cf &x1, cf &x2, cf &x3)
+{
+    cf t0 = cadd(x0, x2), t1 = csub(x0, x2);
+    cf t2 = cadd(x1, x3), t3 = mul_si<SIGN>(csub(x1, x3));
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = cadd(t1, t3);
+    x3 = csub(t1, t3);
+}
+
+// 8-point, decimation in time over (even, odd)
+template <int SIGN>
+__device__ __forceinline__ void fft8(cf (&v)[8])
+{
+    cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4<SIGN>(e0, e1, e2, e3);
+    fft4<SIGN>(o0, o1, o2, o3);
+    o1 = mul_w8_1<SIGN>(o1);
+    o2 = mul_si<SIGN>(o2);
+    o3 = mul_w8_3<SIGN>(o3);
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+// 16-point as 4 x 4: F_r = fft4(x[r], x[r+4], x[r+8], x[r+12]);
+// X[k' + 4k''] = fft4 over r of (W16^{r k'} F_r[k'])
+template <int SIGN>
+__device__ __forceinline__ void fft16(cf (&v)[16])
+{
+    constexpr float c1 = 0.92387953251128675613f; // cos(pi/8)
+    constexpr float s1 = 0.38268343236508977173f; // sin(pi/8)
+    constexpr float sg = (float)SIGN;
+#pragma unroll
+    for (int r = 0; r < 4; r++) fft4<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12]);
+    // now v[r + 4k'] = F_r[k'].  Apply W16^{r k'}:
+    // k' = 1: r=1 -> W16^1, r=2 -> W16^2 = W8^1, r=3 -> W16^3
+    v[5] = cmul(v[5], make_float2(c1, sg * s1));
+    v[6] = mul_w8_1<SIGN>(v[6]);
+    v[7] = cmul(v[7], make_float2(s1, sg * c1));
+    // k' = 2: r=1 -> W8^1, r=2 -> W16^4 = SIGN*i, r=3 -> W16^6 = W8^3
+    v[9] = mul_w8_1<SIGN>(v[9]);
+    v[10] = mul_si<SIGN>(v[10]);
+    v[11] = mul_w8_3<SIGN>(v[11]);
+    // k' = 3: r=1 -> W16^3, r=2 -> W16^6 = W8^3, r=3 -> W16^9 = -W16^1
+    v[13] = cmul(v[13], make_float2(s1, sg * c1));
+    v[14] = mul_w8_3<SIGN>(v[14]);
+    v[15] = cmul(v[15], make_float2(-c1, -sg * s1));
+#pragma unroll
+    for (int k = 0; k < 4; k++) fft4<SIGN>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    // now v[4k' + k''] = X[k' + 4k''] -> transpose to natural order
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = a + 1; b < 4; b++) {
+            cf t = v[4 * a + b];
+            v[4 * a + b] = v[4 * b + a];
+            v[4 * b + a] = t;
+        }
+}
+
+} // namespace wrp

@@ -1,0 +1,479 @@
+// wrp_engine.hip -- host side of libwrp.so: the C ABI of include/wrp.h on top of the two
+// gfx950 kernels in wrp_kernels.h.  Mirrors rpv2.cu's generate_constants / prepare_arys /
+// initialize_streams / copy_matrix_to_device / perform_stage_1..3 / copy_result_to_host
+// (rpv2.cu:283-618) without its per-launch cudaDeviceSynchronize (rpv2.cu:422-569).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wrp.h"
+#include "wrp_kernels.h"
+
+#define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
+
+namespace {
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    float2 *h_iq = nullptr;   // pinned [C][m][n]
+    float2 *d_iq = nullptr;   // device [C][m][n]
+    float2 *d_mid = nullptr;  // device [2][m/2][n]
+    float *d_out = nullptr;   // device [m/2][2]
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    bool loaded = false;      // d_iq holds an uploaded sector
+};
+
+} // namespace
+
+struct wrp_engine {
+    wrp_config cfg;
+    int device = 0;
+    std::string hip_err;
+    // constants (device)
+    float *d_wr = nullptr;    // [m]  range window * c
+    float *d_wd = nullptr;    // [n]
+    float2 *d_tw_m = nullptr; // [m]  exp(-2 pi i k / m)
+    float2 *d_tw_n = nullptr; // [n]  exp(+2 pi i k / n)
+    wrp::MaTaps taps;
+    int taps_pad = 7;
+    // batch workspace
+    hipStream_t stream = nullptr;
+    float2 *d_mid = nullptr;  // [max_batch][2][m/2][n]
+    int max_batch = 0;
+    // slots + host result table [elev][sector][gate][2]
+    std::vector<Slot> slots;
+    float *h_result = nullptr; // pinned
+    // dump scratch
+    void *d_dump = nullptr;
+    size_t dump_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (h)->hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            return (e_ == hipErrorOutOfMemory) ? WRP_ERR_NOMEM : WRP_ERR_HIP;              \
+        }                                                                                  \
+    } while (0)
+
+bool shape_supported(int m, int n) { return m == 1024 && n == 512; }
+
+// rpv2.cu:222-250 generate_hamming_coefficients, kept separable: W[i][j] = wr_c[i] * wd[j]
+void make_window(int m, int n, std::vector<float> &wr_c, std::vector<float> &wd)
+{
+    double p_range = 0, p_doppler = 0;
+    for (int i = 0; i < m; i++) p_range += std::pow(0.53836 - 0.46164 * std::cos(2 * M_PI * i / (m - 1)), 2.0);
+    p_range /= m;
+    for (int j = 0; j < n; j++) p_doppler += std::pow(0.53836 - 0.46164 * std::cos(2 * M_PI * j / (n - 1)), 2.0);
+    p_doppler /= n;
+    const double k_wind = -1 / (16383.5 * m * n * std::sqrt(50.0));
+    const double c = k_wind / std::sqrt(p_range * p_doppler);
+    wr_c.resize(m);
+    wd.resize(n);
+    for (int i = 0; i < m; i++) wr_c[i] = (float)((0.53836 - 0.46164 * std::cos(2 * M_PI * i / (m - 1))) * c);
+    for (int j = 0; j < n; j++) wd[j] = (float)(0.53836 - 0.46164 * std::cos(2 * M_PI * j / (n - 1)));
+}
+
+// rpv2.cu:252-262 generate_ma_coefficients (taps only; the FFT of the taps is not needed
+// because the convolution is evaluated directly)
+void make_taps(int count, wrp::MaTaps &t)
+{
+    double g[9], sum = 0;
+    for (int i = 0; i < count; i++) {
+        g[i] = std::exp(-(std::pow(i - ((count - 1) / 2), 2.0)) / 2);
+        sum += g[i];
+    }
+    for (int i = 0; i < 9; i++) t.g[i] = i < count ? (float)(g[i] / sum) : 0.f;
+}
+
+int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
+                 hipStream_t st, const wrp::DumpPtrs *dump)
+{
+    const wrp_config &c = h->cfg;
+    const int tiles = c.n / wrp::RP_TCOLS;
+    const dim3 gridA(n_sectors * 2 * tiles), blockA(wrp::RP_THREADS);
+    const dim3 gridB(c.m / 2 / wrp::DP_WAVES, n_sectors), blockB(wrp::DP_WAVES * 64);
+    wrp::DumpPtrs none{};
+    none.channel = -1;
+    if (dump) {
+        hipLaunchKernelGGL(wrp::range_pass_1024<true>, gridA, blockA, wrp::RP_LDS_BYTES, st, d_iq, d_mid,
+                           h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, *dump);
+        if (h->taps_pad == 7)
+            hipLaunchKernelGGL((wrp::doppler_pass_512<true, 7>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
+                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, *dump);
+        else
+            hipLaunchKernelGGL((wrp::doppler_pass_512<true, 9>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
+                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, *dump);
+    } else {
+        hipLaunchKernelGGL(wrp::range_pass_1024<false>, gridA, blockA, wrp::RP_LDS_BYTES, st, d_iq, d_mid,
+                           h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, none);
+        if (h->taps_pad == 7)
+            hipLaunchKernelGGL((wrp::doppler_pass_512<false, 7>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
+                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
+        else
+            hipLaunchKernelGGL((wrp::doppler_pass_512<false, 9>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
+                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return WRP_OK;
+}
+
+size_t sector_elems(const wrp_config &c) { return (size_t)c.channels * c.m * c.n; }
+size_t mid_elems(const wrp_config &c) { return (size_t)2 * (c.m / 2) * c.n; }
+
+int destroy_impl(wrp_engine *h)
+{
+    if (!h) return WRP_OK;
+    (void)hipSetDevice(h->device);
+    for (auto &s : h->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.h_iq) (void)hipHostFree(s.h_iq);
+        if (s.d_iq) (void)hipFree(s.d_iq);
+        if (s.d_mid) (void)hipFree(s.d_mid);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->d_mid) (void)hipFree(h->d_mid);
+    if (h->d_dump) (void)hipFree(h->d_dump);
+    if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->d_wr) (void)hipFree(h->d_wr);
+    if (h->d_wd) (void)hipFree(h->d_wd);
+    if (h->d_tw_m) (void)hipFree(h->d_tw_m);
+    if (h->d_tw_n) (void)hipFree(h->d_tw_n);
+    delete h;
+    return WRP_OK;
+}
+
+int create_impl(wrp_engine *h)
+{
+    const wrp_config &c = h->cfg;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // 144 KiB of dynamic LDS for the range pass
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RP_LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RP_LDS_BYTES));
+
+    std::vector<float> wr, wd;
+    make_window(c.m, c.n, wr, wd);
+    std::vector<float2> twm(c.m), twn(c.n);
+    for (int k = 0; k < c.m; k++) twm[k] = make_float2((float)std::cos(2 * M_PI * k / c.m), (float)-std::sin(2 * M_PI * k / c.m));
+    for (int k = 0; k < c.n; k++) twn[k] = make_float2((float)std::cos(2 * M_PI * k / c.n), (float)std::sin(2 * M_PI * k / c.n));
+    make_taps(c.ma_count, h->taps);
+    h->taps_pad = c.ma_count <= 7 ? 7 : 9;
+
+    HIP_TRY(h, hipMalloc(&h->d_wr, sizeof(float) * c.m));
+    HIP_TRY(h, hipMalloc(&h->d_wd, sizeof(float) * c.n));
+    HIP_TRY(h, hipMalloc(&h->d_tw_m, sizeof(float2) * c.m));
+    HIP_TRY(h, hipMalloc(&h->d_tw_n, sizeof(float2) * c.n));
+    HIP_TRY(h, hipMemcpy(h->d_wr, wr.data(), sizeof(float) * c.m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_wd, wd.data(), sizeof(float) * c.n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_tw_m, twm.data(), sizeof(float2) * c.m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_tw_n, twn.data(), sizeof(float2) * c.n, hipMemcpyHostToDevice));
+
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreate(&h->ev0));
+    HIP_TRY(h, hipEventCreate(&h->ev1));
+    h->max_batch = c.max_batch > 0 ? c.max_batch : 16;
+    HIP_TRY(h, hipMalloc(&h->d_mid, sizeof(float2) * mid_elems(c) * h->max_batch));
+
+    const size_t table = (size_t)c.n_elevations * c.n_sectors * (c.m / 2) * 2;
+    HIP_TRY(h, hipHostMalloc(&h->h_result, sizeof(float) * table, hipHostMallocDefault));
+    std::memset(h->h_result, 0, sizeof(float) * table);
+
+    h->slots.resize(c.n_slots);
+    for (auto &s : h->slots) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(h, hipHostMalloc(&s.h_iq, sizeof(float2) * sector_elems(c), hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc(&s.d_iq, sizeof(float2) * sector_elems(c)));
+        HIP_TRY(h, hipMalloc(&s.d_mid, sizeof(float2) * mid_elems(c)));
+        HIP_TRY(h, hipMalloc(&s.d_out, sizeof(float) * (c.m / 2) * 2));
+    }
+    return WRP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void wrp_default_config(wrp_config *cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->m = 1024;           // rpv2.cu:40 n_sweeps
+    cfg->n = 512;            // rpv2.cu:41 n_samples
+    cfg->channels = 2;
+    cfg->n_slots = 2;        // rpv2.cu:728
+    cfg->n_sectors = 143;    // rpv2.cu:39
+    cfg->n_elevations = 9;   // rpv2.cu:42
+    cfg->ma_count = 7;       // rpv2.cu:45
+    cfg->k_range_resolution = 30.f;
+    cfg->k_calibration = 1941.05f;
+    cfg->max_batch = 0;
+    cfg->flags = 0;
+}
+
+int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
+{
+    if (!cfg || !out) return WRP_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
+        cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
+        cfg->flags != 0 || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
+        return WRP_ERR_INVALID;
+    if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return WRP_ERR_HIP;
+    wrp_engine *h = new (std::nothrow) wrp_engine();
+    if (!h) return WRP_ERR_NOMEM;
+    h->cfg = *cfg;
+    h->device = device;
+    int rc = create_impl(h);
+    if (rc != WRP_OK) {
+        destroy_impl(h);
+        return rc;
+    }
+    *out = h;
+    return WRP_OK;
+}
+
+void wrp_destroy(wrp_handle h) { destroy_impl(h); }
+
+const char *wrp_strerror(int status)
+{
+    switch (status) {
+    case WRP_OK: return "ok";
+    case WRP_ERR_INVALID: return "invalid argument";
+    case WRP_ERR_HIP: return "HIP runtime error";
+    case WRP_ERR_NOMEM: return "out of memory";
+    case WRP_ERR_UNSUPPORTED: return "unsupported sector shape";
+    case WRP_ERR_STATE: return "call order violated";
+    default: return "unknown wrp status";
+    }
+}
+
+const char *wrp_last_hip_error(wrp_handle h) { return h ? h->hip_err.c_str() : ""; }
+
+int wrp_pinned_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes)
+{
+    if (!h || slot < 0 || slot >= (int)h->slots.size() || !host_ptr) return WRP_ERR_INVALID;
+    *host_ptr = h->slots[slot].h_iq;
+    if (bytes) *bytes = sizeof(float2) * sector_elems(h->cfg);
+    return WRP_OK;
+}
+
+int wrp_submit(wrp_handle h, int slot, int sector, int elevation)
+{
+    if (!h || slot < 0 || slot >= (int)h->slots.size() || sector < 0 || sector >= h->cfg.n_sectors ||
+        elevation < 0 || elevation >= h->cfg.n_elevations)
+        return WRP_ERR_INVALID;
+    Slot &s = h->slots[slot];
+    if (s.busy) return WRP_ERR_STATE;
+    const wrp_config &c = h->cfg;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(s.d_iq, s.h_iq, sizeof(float2) * sector_elems(c), hipMemcpyHostToDevice, s.stream));
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr);
+    if (rc != WRP_OK) return rc;
+    float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
+    HIP_TRY(h, hipMemcpyAsync(dst, s.d_out, sizeof(float) * (c.m / 2) * 2, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipEventRecord(s.done, s.stream));
+    s.busy = true;
+    s.loaded = true;
+    return WRP_OK;
+}
+
+int wrp_wait(wrp_handle h, int slot)
+{
+    if (!h || slot < 0 || slot >= (int)h->slots.size()) return WRP_ERR_INVALID;
+    Slot &s = h->slots[slot];
+    if (!s.busy) return WRP_ERR_STATE;
+    HIP_TRY(h, hipEventSynchronize(s.done));
+    s.busy = false;
+    return WRP_OK;
+}
+
+int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr)
+{
+    if (!h || !zdb_zdr || sector < 0 || sector >= h->cfg.n_sectors || elevation < 0 ||
+        elevation >= h->cfg.n_elevations)
+        return WRP_ERR_INVALID;
+    *zdb_zdr = h->h_result + ((size_t)elevation * h->cfg.n_sectors + sector) * (h->cfg.m / 2) * 2;
+    return WRP_OK;
+}
+
+int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream)
+{
+    if (!h || !d_iq || !d_out || n_sectors < 0) return WRP_ERR_INVALID;
+    if (n_sectors == 0) return WRP_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const wrp_config &c = h->cfg;
+    const float2 *in = (const float2 *)d_iq;
+    for (int s0 = 0; s0 < n_sectors; s0 += h->max_batch) {
+        const int cnt = std::min(h->max_batch, n_sectors - s0);
+        int rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid,
+                              d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
+        if (rc != WRP_OK) return rc;
+    }
+    return WRP_OK;
+}
+
+int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream)
+{
+    return wrp_process_batch_device(h, d_iq, 1, d_out, stream);
+}
+
+int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *out_host)
+{
+    if (!h || !iq_host || !out_host || n_sectors < 0) return WRP_ERR_INVALID;
+    if (n_sectors == 0) return WRP_OK;
+    const wrp_config &c = h->cfg;
+    HIP_TRY(h, hipSetDevice(h->device));
+    float2 *d_in = nullptr;
+    float *d_out = nullptr;
+    const size_t in_bytes = sizeof(float2) * sector_elems(c) * n_sectors;
+    const size_t out_bytes = sizeof(float) * (c.m / 2) * 2 * (size_t)n_sectors;
+    HIP_TRY(h, hipMalloc(&d_in, in_bytes));
+    hipError_t e = hipMalloc(&d_out, out_bytes);
+    if (e != hipSuccess) { (void)hipFree(d_in); h->hip_err = "hipMalloc(out)"; return WRP_ERR_NOMEM; }
+    int rc = WRP_OK;
+    e = hipMemcpyAsync(d_in, iq_host, in_bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) rc = wrp_process_batch_device(h, d_in, n_sectors, d_out, h->stream);
+    if (e == hipSuccess && rc == WRP_OK) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { h->hip_err = hipGetErrorString(e); return WRP_ERR_HIP; }
+    return rc;
+}
+
+int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_out)
+{
+    if (!h || slot < 0 || slot >= (int)h->slots.size() || !host_out || channel < 0 || channel > 1)
+        return WRP_ERR_INVALID;   // VH (channel 2) is never processed
+    Slot &s = h->slots[slot];
+    if (s.busy || !s.loaded) return WRP_ERR_STATE;
+    const wrp_config &c = h->cfg;
+    size_t bytes = 0;
+    switch (stage) {
+    case WRP_STAGE_01HAMM: case WRP_STAGE_02FFT1: bytes = sizeof(float2) * (size_t)c.m * c.n; break;
+    case WRP_STAGE_03FFT2_NOSHIFT: case WRP_STAGE_03FFT2: bytes = sizeof(float2) * (size_t)(c.m / 2) * c.n; break;
+    case WRP_STAGE_04ABS: case WRP_STAGE_08POW: bytes = sizeof(float) * (size_t)(c.m / 2) * c.n; break;
+    case WRP_STAGE_ROWSUM: bytes = sizeof(float) * (size_t)(c.m / 2); break;
+    default: return WRP_ERR_INVALID;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->dump_bytes < bytes) {
+        if (h->d_dump) (void)hipFree(h->d_dump);
+        h->d_dump = nullptr; h->dump_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_dump, bytes));
+        h->dump_bytes = bytes;
+    }
+    wrp::DumpPtrs d{};
+    d.channel = channel;
+    switch (stage) {
+    case WRP_STAGE_01HAMM: d.hamm = (float2 *)h->d_dump; break;
+    case WRP_STAGE_02FFT1: d.fft1 = (float2 *)h->d_dump; break;
+    case WRP_STAGE_03FFT2_NOSHIFT: d.noshift = (float2 *)h->d_dump; break;
+    case WRP_STAGE_03FFT2: d.fft2 = (float2 *)h->d_dump; break;
+    case WRP_STAGE_04ABS: d.abs2 = (float *)h->d_dump; break;
+    case WRP_STAGE_08POW: d.pow = (float *)h->d_dump; break;
+    case WRP_STAGE_ROWSUM: d.rowsum = (float *)h->d_dump; break;
+    }
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, &d);
+    if (rc != WRP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(host_out, h->d_dump, bytes, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    return WRP_OK;
+}
+
+int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, int iters,
+                          float *ms_total, float *ms_range, float *ms_doppler)
+{
+    if (!h || !d_iq || !d_out || n_sectors <= 0 || iters <= 0 || !ms_total) return WRP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    for (int it = 0; it < iters; it++) {
+        int rc = wrp_process_batch_device(h, d_iq, n_sectors, d_out, h->stream);
+        if (rc != WRP_OK) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
+    if (ms_range || ms_doppler) {
+        // second run: one event pair per launch (adds event overhead, so it is kept out of ms_total)
+        const wrp_config &c = h->cfg;
+        const int tiles = c.n / wrp::RP_TCOLS;
+        float tr = 0.f, td = 0.f;
+        wrp::DumpPtrs none{};
+        none.channel = -1;
+        hipEvent_t e0, e1, e2;
+        HIP_TRY(h, hipEventCreate(&e0));
+        HIP_TRY(h, hipEventCreate(&e1));
+        HIP_TRY(h, hipEventCreate(&e2));
+        for (int it = 0; it < iters; it++) {
+            for (int s0 = 0; s0 < n_sectors; s0 += h->max_batch) {
+                const int cnt = std::min(h->max_batch, n_sectors - s0);
+                const float2 *in = (const float2 *)d_iq + (size_t)s0 * sector_elems(c);
+                float *out = d_out + (size_t)s0 * (c.m / 2) * 2;
+                const dim3 gridA(cnt * 2 * tiles), blockA(wrp::RP_THREADS);
+                const dim3 gridB(c.m / 2 / wrp::DP_WAVES, cnt), blockB(wrp::DP_WAVES * 64);
+                (void)hipEventRecord(e0, h->stream);
+                hipLaunchKernelGGL(wrp::range_pass_1024<false>, gridA, blockA, wrp::RP_LDS_BYTES, h->stream, in,
+                                   h->d_mid, h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, none);
+                (void)hipEventRecord(e1, h->stream);
+                if (h->taps_pad == 7)
+                    hipLaunchKernelGGL((wrp::doppler_pass_512<false, 7>), gridB, blockB, 0, h->stream, h->d_mid, out,
+                                       h->d_tw_n, c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
+                else
+                    hipLaunchKernelGGL((wrp::doppler_pass_512<false, 9>), gridB, blockB, 0, h->stream, h->d_mid, out,
+                                       h->d_tw_n, c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
+                (void)hipEventRecord(e2, h->stream);
+                (void)hipEventSynchronize(e2);
+                float a = 0.f, b = 0.f;
+                (void)hipEventElapsedTime(&a, e0, e1);
+                (void)hipEventElapsedTime(&b, e1, e2);
+                tr += a;
+                td += b;
+            }
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+        HIP_TRY(h, hipGetLastError());
+        if (ms_range) *ms_range = tr;
+        if (ms_doppler) *ms_doppler = td;
+    }
+    return WRP_OK;
+}
+
+int wrp_get_config(wrp_handle h, wrp_config *cfg)
+{
+    if (!h || !cfg) return WRP_ERR_INVALID;
+    *cfg = h->cfg;
+    cfg->max_batch = h->max_batch;
+    return WRP_OK;
+}
+
+size_t wrp_sector_bytes(wrp_handle h) { return h ? sizeof(float2) * sector_elems(h->cfg) : 0; }
+size_t wrp_result_bytes(wrp_handle h) { return h ? sizeof(float) * (size_t)(h->cfg.m / 2) * 2 : 0; }
+size_t wrp_algorithmic_bytes(wrp_handle h)
+{
+    return h ? (size_t)2 * h->cfg.m * h->cfg.n * 8 + (size_t)(h->cfg.m / 2) * 2 * 4 : 0;
+}
+const char *wrp_version(void) { return WRP_VERSION_STRING; }
+
+} // extern "C"
