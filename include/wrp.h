@@ -62,7 +62,8 @@ typedef struct {
     float k_calibration;      /* 1941.05 (rpv2.cu:44) */
     int max_batch;    /* sectors processed per internal chunk of wrp_process_batch_device;
                          sizes the device workspace (0 = default) */
-    int flags;        /* reserved, must be 0 */
+    int flags;        /* bits 0-7: tuning, range-pass column tile (0 = default, 8 or 16);
+                         all other bits reserved, must be 0 */
 } wrp_config;
 
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */

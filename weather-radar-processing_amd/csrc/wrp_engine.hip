@@ -43,6 +43,7 @@ struct wrp_engine {
     float2 *d_tw_n = nullptr; // [n]  exp(+2 pi i k / n)
     wrp::MaTaps taps;
     int taps_pad = 7;
+    int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // batch workspace
     hipStream_t stream = nullptr;
     float2 *d_mid = nullptr;  // [max_batch][2][m/2][n]
@@ -97,34 +98,60 @@ void make_taps(int count, wrp::MaTaps &t)
     for (int i = 0; i < 9; i++) t.g[i] = i < count ? (float)(g[i] / sum) : 0.f;
 }
 
+template <int TCOLS, bool DUMP>
+void launch_range_t(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, hipStream_t st,
+                    const wrp::DumpPtrs &d)
+{
+    typedef wrp::RangeTile<TCOLS> T;
+    const wrp_config &c = h->cfg;
+    const dim3 grid(n_sectors * 2 * (c.n / TCOLS)), block(T::THREADS);
+    hipLaunchKernelGGL((wrp::range_pass_1024<TCOLS, DUMP>), grid, block, T::LDS_BYTES, st, d_iq, d_mid,
+                       h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, d);
+}
+
+void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, hipStream_t st,
+                  const wrp::DumpPtrs *dump)
+{
+    wrp::DumpPtrs none{};
+    none.channel = -1;
+    if (h->range_tcols == 8) {
+        if (dump) launch_range_t<8, true>(h, d_iq, n_sectors, d_mid, st, *dump);
+        else launch_range_t<8, false>(h, d_iq, n_sectors, d_mid, st, none);
+    } else {
+        if (dump) launch_range_t<16, true>(h, d_iq, n_sectors, d_mid, st, *dump);
+        else launch_range_t<16, false>(h, d_iq, n_sectors, d_mid, st, none);
+    }
+}
+
+template <bool DUMP, int TAPS>
+void launch_doppler_t(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_out, hipStream_t st,
+                      const wrp::DumpPtrs &d)
+{
+    const wrp_config &c = h->cfg;
+    const dim3 grid(c.m / 2 / wrp::DP_WAVES, n_sectors), block(wrp::DP_WAVES * 64);
+    hipLaunchKernelGGL((wrp::doppler_pass_512<DUMP, TAPS>), grid, block, 0, st, d_mid, d_out, h->d_tw_n,
+                       c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, d);
+}
+
+void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_out, hipStream_t st,
+                    const wrp::DumpPtrs *dump)
+{
+    wrp::DumpPtrs none{};
+    none.channel = -1;
+    if (h->taps_pad == 7) {
+        if (dump) launch_doppler_t<true, 7>(h, d_mid, n_sectors, d_out, st, *dump);
+        else launch_doppler_t<false, 7>(h, d_mid, n_sectors, d_out, st, none);
+    } else {
+        if (dump) launch_doppler_t<true, 9>(h, d_mid, n_sectors, d_out, st, *dump);
+        else launch_doppler_t<false, 9>(h, d_mid, n_sectors, d_out, st, none);
+    }
+}
+
 int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
                  hipStream_t st, const wrp::DumpPtrs *dump)
 {
-    const wrp_config &c = h->cfg;
-    const int tiles = c.n / wrp::RP_TCOLS;
-    const dim3 gridA(n_sectors * 2 * tiles), blockA(wrp::RP_THREADS);
-    const dim3 gridB(c.m / 2 / wrp::DP_WAVES, n_sectors), blockB(wrp::DP_WAVES * 64);
-    wrp::DumpPtrs none{};
-    none.channel = -1;
-    if (dump) {
-        hipLaunchKernelGGL(wrp::range_pass_1024<true>, gridA, blockA, wrp::RP_LDS_BYTES, st, d_iq, d_mid,
-                           h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, *dump);
-        if (h->taps_pad == 7)
-            hipLaunchKernelGGL((wrp::doppler_pass_512<true, 7>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
-                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, *dump);
-        else
-            hipLaunchKernelGGL((wrp::doppler_pass_512<true, 9>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
-                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, *dump);
-    } else {
-        hipLaunchKernelGGL(wrp::range_pass_1024<false>, gridA, blockA, wrp::RP_LDS_BYTES, st, d_iq, d_mid,
-                           h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, none);
-        if (h->taps_pad == 7)
-            hipLaunchKernelGGL((wrp::doppler_pass_512<false, 7>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
-                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
-        else
-            hipLaunchKernelGGL((wrp::doppler_pass_512<false, 9>), gridB, blockB, 0, st, d_mid, d_out, h->d_tw_n,
-                               c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
-    }
+    launch_range(h, d_iq, n_sectors, d_mid, st, dump);
+    launch_doppler(h, d_mid, n_sectors, d_out, st, dump);
     HIP_TRY(h, hipGetLastError());
     return WRP_OK;
 }
@@ -163,11 +190,16 @@ int create_impl(wrp_engine *h)
 {
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipSetDevice(h->device));
-    // 144 KiB of dynamic LDS for the range pass
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RP_LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RP_LDS_BYTES));
+    // up to 144 KiB of dynamic LDS for the range pass
+    h->range_tcols = (c.flags & 0xff) == 8 ? 8 : 16;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<16>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<16>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<8, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<8>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<8, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<8>::LDS_BYTES));
 
     std::vector<float> wr, wd;
     make_window(c.m, c.n, wr, wd);
@@ -235,7 +267,7 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        cfg->flags != 0 || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
+        (cfg->flags & ~0xff) != 0 || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -418,10 +450,7 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
     if (ms_range || ms_doppler) {
         // second run: one event pair per launch (adds event overhead, so it is kept out of ms_total)
         const wrp_config &c = h->cfg;
-        const int tiles = c.n / wrp::RP_TCOLS;
         float tr = 0.f, td = 0.f;
-        wrp::DumpPtrs none{};
-        none.channel = -1;
         hipEvent_t e0, e1, e2;
         HIP_TRY(h, hipEventCreate(&e0));
         HIP_TRY(h, hipEventCreate(&e1));
@@ -431,18 +460,10 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
                 const int cnt = std::min(h->max_batch, n_sectors - s0);
                 const float2 *in = (const float2 *)d_iq + (size_t)s0 * sector_elems(c);
                 float *out = d_out + (size_t)s0 * (c.m / 2) * 2;
-                const dim3 gridA(cnt * 2 * tiles), blockA(wrp::RP_THREADS);
-                const dim3 gridB(c.m / 2 / wrp::DP_WAVES, cnt), blockB(wrp::DP_WAVES * 64);
                 (void)hipEventRecord(e0, h->stream);
-                hipLaunchKernelGGL(wrp::range_pass_1024<false>, gridA, blockA, wrp::RP_LDS_BYTES, h->stream, in,
-                                   h->d_mid, h->d_wr, h->d_wd, h->d_tw_m, c.n, c.channels, none);
+                launch_range(h, in, cnt, h->d_mid, h->stream, nullptr);
                 (void)hipEventRecord(e1, h->stream);
-                if (h->taps_pad == 7)
-                    hipLaunchKernelGGL((wrp::doppler_pass_512<false, 7>), gridB, blockB, 0, h->stream, h->d_mid, out,
-                                       h->d_tw_n, c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
-                else
-                    hipLaunchKernelGGL((wrp::doppler_pass_512<false, 9>), gridB, blockB, 0, h->stream, h->d_mid, out,
-                                       h->d_tw_n, c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, none);
+                launch_doppler(h, h->d_mid, cnt, out, h->stream, nullptr);
                 (void)hipEventRecord(e2, h->stream);
                 (void)hipEventSynchronize(e2);
                 float a = 0.f, b = 0.f;

@@ -30,30 +30,37 @@ struct DumpPtrs {       // all optional (nullptr = skip); one sector, one channe
 struct MaTaps { float g[9]; };
 
 // ---------------------------------------------------------------------------------------------
-// range pass, m = 1024 = 16 x 8 x 8, 16 columns per workgroup, 512 threads.
+// range pass, m = 1024 = 16 x 8 x 8; TCOLS = 16 columns per 512-thread workgroup (1 per CU) or
+// 8 columns per 256-thread workgroup (2 per CU).
 //
 // In-place decimation-in-frequency over positions p of a column:
 //   stage 1 (registers, straight from HBM): lane owns rows p0 + 64 r, r < 16   -> radix 16,
 //           twiddle W_1024^{p0 k1}, result to LDS position k1*64 + p0
 //   stage 2 (LDS): rows k1*64 + p1 + 8 r, r < 8  -> radix 8, twiddle W_64^{p1 k2}, in place
 //   stage 3 (LDS): rows k1*64 + k2*8 + r, r < 8  -> radix 8; output row k = k1 + 16 k2 + 128 k3
-// LDS image: [position][16 columns] complex, 128 B per position, plus 128 B of padding after
-// every 8 positions so that stage 3's ds_read_b128 (lanes = 8 column pairs x 8 k2) is
+// LDS image: [position][TCOLS columns] complex, plus one position of padding after
+// every 8 positions so that stage 3's ds_read_b128 (lanes = column pairs x 8 k2) is
 // bank-conflict free; stages 1 and 2 touch whole contiguous 1 KiB rows per wave-instruction.
 // ---------------------------------------------------------------------------------------------
 constexpr int RP_M = 1024;
-constexpr int RP_TCOLS = 16;
-constexpr int RP_THREADS = 512;
-constexpr int RP_BLK_BYTES = 8 * 128 + 128;                  // 8 positions + pad
-constexpr int RP_LDS_BYTES = (RP_M / 8) * RP_BLK_BYTES;      // 147456
 
-__device__ __forceinline__ int rp_addr(int pos, int colpair)   // byte address of a float4
-{
-    return (pos >> 3) * RP_BLK_BYTES + (pos & 7) * 128 + colpair * 16;
-}
+template <int TCOLS>
+struct RangeTile {
+    static constexpr int CP = TCOLS / 2;              // column pairs (one float4) per row segment
+    static constexpr int ROWS_PER_WAVE = 64 / CP;     // row segments one wave-instruction covers
+    static constexpr int WAVES = 64 / ROWS_PER_WAVE;  // waves so that the block covers 64 rows
+    static constexpr int THREADS = 64 * WAVES;        // 512 (16 columns) or 256 (8 columns)
+    static constexpr int ROW_BYTES = TCOLS * 8;       // bytes of one position in LDS
+    static constexpr int BLK_BYTES = 9 * ROW_BYTES;   // 8 positions + one position of padding
+    static constexpr int LDS_BYTES = (RP_M / 8) * BLK_BYTES;   // 147456 / 73728
+    static __device__ __forceinline__ int addr(int pos, int colpair)   // byte address of a float4
+    {
+        return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + colpair * 16;
+    }
+};
 
-template <bool DUMP>
-__global__ __launch_bounds__(RP_THREADS) void range_pass_1024(
+template <int TCOLS, bool DUMP>
+__global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
     const float2 *__restrict__ iq,   // [S][C][1024][n]
     float2 *__restrict__ mid,        // [S][2][512][n]
     const float *__restrict__ wr_c,  // [1024]  range window * c
@@ -61,10 +68,18 @@ __global__ __launch_bounds__(RP_THREADS) void range_pass_1024(
     const float2 *__restrict__ tw,   // [1024]  exp(-2 pi i k / 1024)
     int n, int channels, DumpPtrs dump)
 {
+    typedef RangeTile<TCOLS> T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int tiles = n / RP_TCOLS;
+    const int tiles = n / TCOLS;
     int b = blockIdx.x;
+    if (TCOLS == 8) {
+        // two 8-column tiles share every 128-byte line: give the pair to blocks x and x + 8,
+        // which the dispatcher places on the same XCD, so that its L2 serves the second read
+        // (speed only -- any placement computes the same result)
+        const int x = b & 15;
+        b = (b & ~15) + ((x & 7) << 1) + (x >> 3);
+    }
     const int tile = b % tiles; b /= tiles;
     const int ch = b % 2;       b /= 2;
     const int sec = b;
@@ -76,9 +91,9 @@ __global__ __launch_bounds__(RP_THREADS) void range_pass_1024(
     // ---- stage 1 ------------------------------------------------------------------------
     {
         const int w = tid >> 6, l = tid & 63;
-        const int rowin = l >> 3, cp = l & 7;
-        const int p0 = w * 8 + rowin;
-        const int col0 = tile * RP_TCOLS + cp * 2;
+        const int rowin = l / T::CP, cp = l % T::CP;
+        const int p0 = w * T::ROWS_PER_WAVE + rowin;
+        const int col0 = tile * TCOLS + cp * 2;
         float4 v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++)
@@ -100,17 +115,17 @@ __global__ __launch_bounds__(RP_THREADS) void range_pass_1024(
         }
         fft16<-1>(a);
         fft16<-1>(c);
-        *reinterpret_cast<float4 *>(smem + rp_addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
+        *reinterpret_cast<float4 *>(smem + T::addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++) {
             const cf t = tw[(p0 * k1) & (RP_M - 1)];
             const cf x = cmul(a[k1], t), y = cmul(c[k1], t);
-            *reinterpret_cast<float4 *>(smem + rp_addr(k1 * 64 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
+            *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
         }
     }
     __syncthreads();
 
-    const int cp = tid & 7, q = (tid >> 3) & 7, kb = tid >> 6;
+    const int cp = tid % T::CP, q = (tid / T::CP) & 7, kb = tid / (T::CP * 8);
     // ---- stage 2 ------------------------------------------------------------------------
 #pragma unroll
     for (int it = 0; it < 2; it++) {
@@ -118,31 +133,31 @@ __global__ __launch_bounds__(RP_THREADS) void range_pass_1024(
         cf a[8], c[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const float4 u = *reinterpret_cast<const float4 *>(smem + rp_addr(k1 * 64 + p1 + 8 * r, cp));
+            const float4 u = *reinterpret_cast<const float4 *>(smem + T::addr(k1 * 64 + p1 + 8 * r, cp));
             a[r] = make_float2(u.x, u.y);
             c[r] = make_float2(u.z, u.w);
         }
         fft8<-1>(a);
         fft8<-1>(c);
-        *reinterpret_cast<float4 *>(smem + rp_addr(k1 * 64 + p1, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
+        *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p1, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
 #pragma unroll
         for (int k2 = 1; k2 < 8; k2++) {
             const cf t = tw[(16 * p1 * k2) & (RP_M - 1)];
             const cf x = cmul(a[k2], t), y = cmul(c[k2], t);
-            *reinterpret_cast<float4 *>(smem + rp_addr(k1 * 64 + p1 + 8 * k2, cp)) = make_float4(x.x, x.y, y.x, y.y);
+            *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p1 + 8 * k2, cp)) = make_float4(x.x, x.y, y.x, y.y);
         }
     }
     __syncthreads();
 
     // ---- stage 3 + store ----------------------------------------------------------------
-    const int col0 = tile * RP_TCOLS + cp * 2;
+    const int col0 = tile * TCOLS + cp * 2;
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int k1 = kb + 8 * it, k2 = q;
         cf a[8], c[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const float4 u = *reinterpret_cast<const float4 *>(smem + rp_addr(k1 * 64 + k2 * 8 + r, cp));
+            const float4 u = *reinterpret_cast<const float4 *>(smem + T::addr(k1 * 64 + k2 * 8 + r, cp));
             a[r] = make_float2(u.x, u.y);
             c[r] = make_float2(u.z, u.w);
         }
