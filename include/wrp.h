@@ -63,8 +63,14 @@ typedef struct {
     int max_batch;    /* sectors processed per internal chunk of wrp_process_batch_device;
                          sizes the device workspace (0 = default) */
     int flags;        /* bits 0-7: tuning, range-pass column tile (0 = default, 8 or 16);
-                         all other bits reserved, must be 0 */
+                         WRP_FLAG_FUSED: batches of >= 8 sectors run as ONE persistent launch whose
+                         XCD teams keep the intermediate in L2; other bits reserved, must be 0 */
 } wrp_config;
+
+#define WRP_FLAG_FUSED 0x100
+/* batches larger than max_batch: run the range pass of chunk k+1 beside the Doppler pass of
+ * chunk k on two internal streams (joined to the caller's stream by events) */
+#define WRP_FLAG_OVERLAP 0x200
 
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
 typedef enum {
@@ -130,6 +136,12 @@ int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_ou
  * Doppler-pass kernels measured by per-launch event pairs in a second, separate run. */
 int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                           int iters, float *ms_total, float *ms_range, float *ms_doppler);
+
+/* Diagnostics: one fused launch with in-kernel phase stamps (100 MHz ticks) copied to
+ * host_stamps[n_CUs][16 tasks][8]: 0 tile ready, 1 stages 1-2 done, 2 mid buffer free, 3 tile stored,
+ * 4 team barrier passed, 5 Doppler rows done.  Synchronous; timing of this call is not representative. */
+int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
+                           unsigned long long *host_stamps, size_t host_count);
 
 /* Introspection for harnesses. */
 int wrp_get_config(wrp_handle h, wrp_config *cfg);

@@ -126,6 +126,20 @@ def test_batch_larger_than_workspace_chunk(wrp, sectors):
         assert e.process_host(batch[:0]).shape == (0, 512, 2)       # empty batch is a no-op
 
 
+def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, sectors):
+    """WRP_FLAG_FUSED: one persistent launch, XCD teams, intermediate in L2 -- same device functions,
+    so every bit must match the two-kernel path, for batch sizes that do and do not divide evenly
+    among the teams, and when the same engine is reused (control block re-zeroed per launch)."""
+    with wrp.Engine(device=0, n_slots=1, flags=0x100) as ef, wrp.Engine(device=0, n_slots=1) as e2:
+        for count in (8, 19):
+            batch = np.stack([sectors[(3 * k + 1) % 3] * np.float32(1 + 0.25 * (k % 5)) for k in range(count)])
+            a = ef.process_host(batch)
+            b = e2.process_host(batch)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), count
+        # fewer than 8 sectors falls back to the two-kernel path by design
+        assert np.array_equal(ef.process_host(batch[:3]), b[:3])
+
+
 def test_vh_plane_is_carried_but_ignored(wrp, sectors):
     """channels = 3 is the reference's Dimension4(n, m, 3, streams) layout; VH feeds no output."""
     with wrp.Engine(device=0, n_slots=1, channels=3) as e3, wrp.Engine(device=0, n_slots=1) as e2:

@@ -1,14 +1,19 @@
-// wrp_kernels.h -- the two fused HIP kernels of the per-sector chain (gfx950).
+// wrp_kernels.h -- the HIP kernels of the per-sector chain (gfx950, wave64).
 //
-//   range_pass   : Hamming window (a2) + range FFT along i (a3), one workgroup per
-//                  (sector, channel, 16-column tile); writes rows k < m/2 only.
-//   doppler_pass : mean removal (a4), Doppler FFT + conj + shift + clip (a5), |.|^2 (a6),
-//                  7-tap causal circular MA (a7), row sum (a8), Zdb/Zdr (a9); one wave
-//                  per range gate, both polarisations in the same wave.
+//   range_pass_1024   : Hamming window (a2) + range FFT along i (a3), one workgroup per
+//                       (sector, channel, column tile); writes gates k < m/2 only.
+//   doppler_pass_512  : mean removal (a4), Doppler FFT + conj + shift + clip (a5), |.|^2 (a6),
+//                       7-tap causal circular MA (a7), row sum (a8), Zdb/Zdr (a9); one wave per
+//                       range gate, both polarisations in the same wave.
+//   fused_sector_1024x512 : both passes in ONE persistent launch; the workgroups of one XCD form
+//                       a team that runs the range tiles and then the Doppler rows of a
+//                       sector-channel, so the 2 MiB intermediate never leaves that XCD's L2.
 //
-// Reference semantics: read.cc:133-345 / rpv2.cu:86-213,409-570 (see DESIGN.md §2 for the
-// per-stage mapping).  No rocFFT/hipFFT: the FFTs are LDS-resident mixed-radix passes
-// (16x8x8 for m = 1024, 8x8x8 for n = 512) built from fft_radix.h.
+// Reference semantics: read.cc:133-345 / rpv2.cu:86-213,409-570 (DESIGN.md §1 maps every stage).
+// No rocFFT/hipFFT: the FFTs are LDS-resident mixed-radix passes (16x8x8 for m = 1024, 8x8x8 for
+// n = 512) built from fft_radix.h.  All three kernels share the device functions below and the
+// library is built with -ffp-contract=off, so the fused launch is bit-identical to the
+// two-kernel path.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,19 +34,68 @@ struct DumpPtrs {       // all optional (nullptr = skip); one sector, one channe
 
 struct MaTaps { float g[9]; };
 
-// ---------------------------------------------------------------------------------------------
-// range pass, m = 1024 = 16 x 8 x 8; TCOLS = 16 columns per 512-thread workgroup (1 per CU) or
-// 8 columns per 256-thread workgroup (2 per CU).
+struct RangeConsts {
+    const float *wr_c;   // [1024]  range window * c
+    const float *wd;     // [n]     Doppler window
+    const float2 *tw;    // [1024]  exp(-2 pi i k / 1024)
+};
+
+// ---- buffer addressing: descriptor (SGPRs) + ONE 32-bit lane offset + scalar offset ---------
+// The compiler turns `uniform_ptr + const + lane` into per-access 64-bit VGPR addresses (32 VGPRs
+// for a 16-load tile); raw buffer operations keep base and per-access offset in SGPRs.  The
+// descriptor must be built from values the compiler KNOWS are wave-uniform (readfirstlane), or
+// every access becomes a waterfall loop.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int AUX_SC1 = 16;   // L1-bypassing access (served by the XCD's L2)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)   // p, bytes wave-uniform
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+// NB: convert whole vectors -- element-wise __builtin_bit_cast(float, u.x) on the builtin's result
+// makes hipcc (ROCm 7.2) shrink the access to a single dword.
+__device__ __forceinline__ float4 buf_load_f4(rsrc_t r, int voff, int soff)
+{
+    const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+// ALWAYS pass soff = 0 (an immediate): with an SGPR soffset hipcc (ROCm 7.2) schedules a VALU
+// write to the first data VGPR directly behind the 128-bit store without the wait state gfx9
+// requires, and the store then carries the new value (seen as 0.07 dB errors in isolated gates).
+__device__ __forceinline__ void buf_store_f4(rsrc_t r, int voff, int soff, float4 f)
+{
+    v4f t;
+    t.x = f.x; t.y = f.y; t.z = f.z; t.w = f.w;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), r, voff, soff, 0);
+}
+template <int AUX>
+__device__ __forceinline__ float2 buf_load_f2(rsrc_t r, int voff, int soff)
+{
+    const v2f f = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+    return make_float2(f.x, f.y);
+}
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// =============================================================================================
+// range tile, m = 1024 = 16 x 8 x 8; TCOLS = 16 columns per 512-thread workgroup or 8 columns
+// per 256-thread workgroup.
 //
 // In-place decimation-in-frequency over positions p of a column:
 //   stage 1 (registers, straight from HBM): lane owns rows p0 + 64 r, r < 16   -> radix 16,
 //           twiddle W_1024^{p0 k1}, result to LDS position k1*64 + p0
 //   stage 2 (LDS): rows k1*64 + p1 + 8 r, r < 8  -> radix 8, twiddle W_64^{p1 k2}, in place
 //   stage 3 (LDS): rows k1*64 + k2*8 + r, r < 8  -> radix 8; output row k = k1 + 16 k2 + 128 k3
-// LDS image: [position][TCOLS columns] complex, plus one position of padding after
-// every 8 positions so that stage 3's ds_read_b128 (lanes = column pairs x 8 k2) is
-// bank-conflict free; stages 1 and 2 touch whole contiguous 1 KiB rows per wave-instruction.
-// ---------------------------------------------------------------------------------------------
+// LDS image: [position][TCOLS columns] complex, plus one position of padding after every 8
+// positions so that stage 3's ds_read_b128 (lanes = column pairs x 8 k2) is bank-conflict free;
+// stages 1 and 2 touch whole contiguous 1 KiB rows per wave-instruction.  The padding is not
+// wasted: the 1024-entry twiddle table lives in it (tw_addr), so twiddles are LDS reads
+// (lgkmcnt) instead of dependent global loads (vmcnt, in order behind the tile prefetch).
+// The range window wr_c (4 KiB) sits right behind the image.
+// =============================================================================================
 constexpr int RP_M = 1024;
 
 template <int TCOLS>
@@ -52,84 +106,106 @@ struct RangeTile {
     static constexpr int THREADS = 64 * WAVES;        // 512 (16 columns) or 256 (8 columns)
     static constexpr int ROW_BYTES = TCOLS * 8;       // bytes of one position in LDS
     static constexpr int BLK_BYTES = 9 * ROW_BYTES;   // 8 positions + one position of padding
-    static constexpr int LDS_BYTES = (RP_M / 8) * BLK_BYTES;   // 147456 / 73728
+    static constexpr int IMG_BYTES = (RP_M / 8) * BLK_BYTES;   // 147456 / 73728
+    static constexpr int OFF_WR = IMG_BYTES;                    // float wr_c[1024]
+    static constexpr int LDS_BYTES = IMG_BYTES + RP_M * 4;      // 151552 / 77824
+    static constexpr int TW_PER_PAD = ROW_BYTES / 8;            // twiddle entries per padding row (16 / 8)
+    static constexpr int TW_BLK0 = TCOLS == 16 ? 32 : 0;        // 16 cols: pads of blocks 32..95 (blocks 0..31
+                                                                // are re-used as wave buffers by the fused launch)
     static __device__ __forceinline__ int addr(int pos, int colpair)   // byte address of a float4
     {
         return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + colpair * 16;
     }
+    static __device__ __forceinline__ int tw_addr(int e)               // byte address of twiddle e < 1024
+    {
+        return (TW_BLK0 + e / TW_PER_PAD) * BLK_BYTES + 8 * ROW_BYTES + (e % TW_PER_PAD) * 8;
+    }
 };
 
-template <int TCOLS, bool DUMP>
-__global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
-    const float2 *__restrict__ iq,   // [S][C][1024][n]
-    float2 *__restrict__ mid,        // [S][2][512][n]
-    const float *__restrict__ wr_c,  // [1024]  range window * c
-    const float *__restrict__ wd,    // [n]     Doppler window
-    const float2 *__restrict__ tw,   // [1024]  exp(-2 pi i k / 1024)
-    int n, int channels, DumpPtrs dump)
+// copy the twiddle and window tables into LDS (once per workgroup; caller barriers afterwards)
+template <int TCOLS>
+__device__ __forceinline__ void range_tables_to_lds(unsigned char *smem, const RangeConsts &rc)
 {
     typedef RangeTile<TCOLS> T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int tiles = n / TCOLS;
-    int b = blockIdx.x;
-    if (TCOLS == 8) {
-        // two 8-column tiles share every 128-byte line: give the pair to blocks x and x + 8,
-        // which the dispatcher places on the same XCD, so that its L2 serves the second read
-        // (speed only -- any placement computes the same result)
-        const int x = b & 15;
-        b = (b & ~15) + ((x & 7) << 1) + (x >> 3);
+    for (int e = threadIdx.x; e < RP_M; e += T::THREADS) {
+        *reinterpret_cast<float2 *>(smem + T::tw_addr(e)) = rc.tw[e];
+        reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
     }
-    const int tile = b % tiles; b /= tiles;
-    const int ch = b % 2;       b /= 2;
-    const int sec = b;
+}
 
-    const float2 *src = iq + ((size_t)sec * channels + ch) * RP_M * (size_t)n;
-    float2 *dst = mid + ((size_t)sec * 2 + ch) * (RP_M / 2) * (size_t)n;
-    const bool do_dump = DUMP && dump.channel == ch && sec == 0;
+// issue the 16 row loads of this lane's two columns (rows p0 + 64 r) and its two Doppler-window values
+template <int TCOLS>
+// valid = false (wave-uniform): the descriptor gets zero records, the hardware drops all 17 loads
+// (they return 0) -- a branch-free way to skip a prefetch, because hipcc waits vmcnt(0) for
+// everything in flight at the first use behind a load that sits in a conditional block.
+__device__ __forceinline__ void range_load(const float2 *src /* wave-uniform */, int n, int col_base,
+                                           const float *wd, float4 (&v)[16], float2 &wdv, bool valid = true)
+{
+    typedef RangeTile<TCOLS> T;
+    const int w = wave_id(), l = threadIdx.x & 63;
+    const int p0 = w * T::ROWS_PER_WAVE + l / T::CP;
+    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * n * 8u : 0u);
+    const int voff = (p0 * n + col_base + (l % T::CP) * 2) * 8;
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = buf_load_f4(rs, voff, 64 * r * n * 8);
+    wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + (l % T::CP) * 2) * 4, 0);
+}
 
-    // ---- stage 1 ------------------------------------------------------------------------
+// stage 1 + stage 2 (ends with the tile in LDS, positions k1*64 + p1 + 8 k2, after a barrier)
+template <int TCOLS, bool DUMP>
+__device__ __forceinline__ void range_stage12(unsigned char *smem, float4 (&v)[16], float2 wdv, int n, int col_base,
+                                              bool do_dump, const DumpPtrs &dump)
+{
+    typedef RangeTile<TCOLS> T;
+    const int tid = threadIdx.x;
     {
         const int w = tid >> 6, l = tid & 63;
-        const int rowin = l / T::CP, cp = l % T::CP;
-        const int p0 = w * T::ROWS_PER_WAVE + rowin;
-        const int col0 = tile * TCOLS + cp * 2;
-        float4 v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            v[r] = *reinterpret_cast<const float4 *>(&src[(size_t)(p0 + 64 * r) * n + col0]);
-        const float2 wdv = *reinterpret_cast<const float2 *>(&wd[col0]);
+        const int cp = l % T::CP;
+        int p0 = w * T::ROWS_PER_WAVE + l / T::CP;
+        // opaque to the optimiser: inside the persistent launch the ~50 per-lane LDS addresses
+        // derived from p0 / p1 / k2 would otherwise be hoisted out of the task loop and spilled
+        asm volatile("" : "+v"(p0));
+        const int col0 = col_base + cp * 2;
+        const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
         cf a[16], c[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float wrow = wr_c[p0 + 64 * r];
+            const float wrow = s_wr[p0 + 64 * r];
             const float w0 = wrow * wdv.x, w1 = wrow * wdv.y;
             a[r] = make_float2(v[r].x * w0, v[r].y * w0);
             c[r] = make_float2(v[r].z * w1, v[r].w * w1);
         }
-        if (do_dump && dump.hamm) {
+        if (DUMP && do_dump && dump.hamm) {
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 *reinterpret_cast<float4 *>(&dump.hamm[(size_t)(p0 + 64 * r) * n + col0]) =
                     make_float4(a[r].x, a[r].y, c[r].x, c[r].y);
         }
+        cf tw1[16];   // all 15 twiddles requested in one batch, ahead of the butterflies (one LDS latency)
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++)
+            tw1[k1] = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
         fft16<-1>(a);
         fft16<-1>(c);
         *reinterpret_cast<float4 *>(smem + T::addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++) {
-            const cf t = tw[(p0 * k1) & (RP_M - 1)];
+            const cf t = tw1[k1];
             const cf x = cmul(a[k1], t), y = cmul(c[k1], t);
             *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
         }
     }
     __syncthreads();
-
-    const int cp = tid % T::CP, q = (tid / T::CP) & 7, kb = tid / (T::CP * 8);
-    // ---- stage 2 ------------------------------------------------------------------------
+    const int cp = tid % T::CP, kb = tid / (T::CP * 8);
+    int p1 = (tid / T::CP) & 7;
+    asm volatile("" : "+v"(p1));
+    cf tw2[8];   // W_64^{p1 k2}: one batch of LDS reads for both items
+#pragma unroll
+    for (int k2 = 1; k2 < 8; k2++)
+        tw2[k2] = *reinterpret_cast<const float2 *>(smem + T::tw_addr((16 * p1 * k2) & (RP_M - 1)));
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const int k1 = kb + 8 * it, p1 = q;
+        const int k1 = kb + 8 * it;
         cf a[8], c[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -142,18 +218,30 @@ __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
         *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p1, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
 #pragma unroll
         for (int k2 = 1; k2 < 8; k2++) {
-            const cf t = tw[(16 * p1 * k2) & (RP_M - 1)];
+            const cf t = tw2[k2];
             const cf x = cmul(a[k2], t), y = cmul(c[k2], t);
             *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p1 + 8 * k2, cp)) = make_float4(x.x, x.y, y.x, y.y);
         }
     }
     __syncthreads();
+}
 
-    // ---- stage 3 + store ----------------------------------------------------------------
-    const int col0 = tile * TCOLS + cp * 2;
+// stage 3: last radix-8 and the store of gates k < m/2 (the chain never reads the rest, rpv2.cu:502)
+template <int TCOLS, bool DUMP>
+__device__ __forceinline__ void range_stage3(const unsigned char *smem, float2 *dst /* wave-uniform */, int n,
+                                             int col_base, bool do_dump, const DumpPtrs &dump)
+{
+    typedef RangeTile<TCOLS> T;
+    const int tid = threadIdx.x;
+    const int cp = tid % T::CP, kb = tid / (T::CP * 8);
+    int k2 = (tid / T::CP) & 7;
+    asm volatile("" : "+v"(k2));
+    const int col0 = col_base + cp * 2;
+    const rsrc_t rd = make_rsrc(dst, (unsigned)(RP_M / 2) * n * 8u);
+    const int voff = ((kb + 16 * k2) * n + col0) * 8;   // row k1 + 16 k2 at it = 0; scalar offsets below
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const int k1 = kb + 8 * it, k2 = q;
+        const int k1 = kb + 8 * it;
         cf a[8], c[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -165,10 +253,9 @@ __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
         fft8<-1>(c);
         const int k0 = k1 + 16 * k2;
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++)   // rows k < m/2 only: the chain never reads the rest (rpv2.cu:502)
-            *reinterpret_cast<float4 *>(&dst[(size_t)(k0 + 128 * k3) * n + col0]) =
-                make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y);
-        if (do_dump && dump.fft1) {
+        for (int k3 = 0; k3 < 4; k3++)   // row offset in the VGPR, soffset 0: see buf_store_f4
+            buf_store_f4(rd, voff + (8 * it + 128 * k3) * n * 8, 0, make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y));
+        if (DUMP && do_dump && dump.fft1) {
 #pragma unroll
             for (int k3 = 0; k3 < 8; k3++)
                 *reinterpret_cast<float4 *>(&dump.fft1[(size_t)(k0 + 128 * k3) * n + col0]) =
@@ -177,33 +264,193 @@ __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// doppler pass, n = 512 = 8 x 8 x 8, one wave per range gate (both channels), 4 waves per block.
-//
-// Wave-private LDS, no workgroup barrier anywhere.  Position p of the in-place DIF lives at
-// element p + (p >> 3) (one 8-byte pad per 8 elements): stage 1 writes, stage 2 and stage 3
-// ds_read_b64 are then conflict free per 32-lane group.
-// ---------------------------------------------------------------------------------------------
+template <int TCOLS, bool DUMP>
+__global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
+    const float2 *__restrict__ iq,   // [S][C][1024][n]
+    float2 *__restrict__ mid,        // [S][2][512][n]
+    RangeConsts rc, int n, int channels, DumpPtrs dump)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tiles = n / TCOLS;
+    int b = blockIdx.x;
+    if (TCOLS == 8) {
+        // two 8-column tiles share every 128-byte line: give the pair to blocks x and x + 8,
+        // which the dispatcher places on the same XCD, so that its L2 serves the second read
+        // (speed only -- any placement computes the same result)
+        const int x = b & 15;
+        b = (b & ~15) + ((x & 7) << 1) + (x >> 3);
+    }
+    const int tile = b % tiles; b /= tiles;
+    const int ch = b % 2;       b /= 2;
+    const int sec = b;
+    const float2 *src = iq + ((size_t)sec * channels + ch) * RP_M * (size_t)n;
+    float2 *dst = mid + ((size_t)sec * 2 + ch) * (RP_M / 2) * (size_t)n;
+    const bool do_dump = DUMP && dump.channel == ch && sec == 0;
+    float4 v[16];
+    float2 wdv;
+    range_load<TCOLS>(src, n, tile * TCOLS, rc.wd, v, wdv);      // HBM requests first ...
+    range_tables_to_lds<TCOLS>(smem, rc);                        // ... tables while they fly
+    __syncthreads();
+    range_stage12<TCOLS, DUMP>(smem, v, wdv, n, tile * TCOLS, do_dump, dump);
+    range_stage3<TCOLS, DUMP>(smem, dst, n, tile * TCOLS, do_dump, dump);
+}
+
+// =============================================================================================
+// Doppler row, n = 512 = 8 x 8 x 8, one wave per row, wave-private LDS, no workgroup barrier.
+// Twiddles come from a 512-entry LDS table at the point of use (14 ds_read_b64 per row).
+// =============================================================================================
 constexpr int DP_N = 512;
 constexpr int DP_WAVES = 4;
-constexpr int DP_ELEMS = DP_N + DP_N / 8;   // padded complex elements per wave buffer (576)
+constexpr int DP_ELEMS = DP_N + DP_N / 8;   // padded complex elements per wave buffer (576 = 4608 B)
 
-__device__ __forceinline__ int dp_idx(int pos) { return pos + (pos >> 3); }
+// element index of position p: two elements of padding per 16 (tools/lds_banks.py: stage-2/3
+// reads and stage-2 writes conflict free, stage-1 writes 1.5x -- the best of the searched maps)
+__device__ __forceinline__ int dp_idx(int pos) { return pos + 2 * (pos >> 4); }
+// float index of |.|^2 bin j: 4 floats of padding per 8 -> b32 writes and b128 reads conflict free
+__device__ __forceinline__ int dp_fidx(int j) { return j + 4 * (j >> 3); }
+
+struct TagTrue { static constexpr bool value = true; };
+struct TagFalse { static constexpr bool value = false; };
 
 __device__ __forceinline__ void wave_lds_fence()
 {
-    // LDS operations of one wave execute in issue order; this only stops the compiler from
-    // moving accesses across the point where lanes exchange data.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // LDS operations of one wave execute in issue order, so lanes may read what other lanes of the
+    // same wave wrote earlier without any wait; this only stops the COMPILER from moving memory
+    // accesses across the exchange point (no instruction is emitted).
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 64 lanes without touching LDS: DPP inside each row of 16, v_readlane across rows
 __device__ __forceinline__ float wave_sum(float v)
 {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
+// lane l takes j = l + 64 r.  SC1 = L1-bypassing loads (rows written by other CUs in this launch)
+template <bool SC1>
+__device__ __forceinline__ void doppler_load_row(const float2 *row /* wave-uniform */, int l, cf (&x)[8])
+{
+    const rsrc_t rs = make_rsrc(row, DP_N * 8u);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int r = 0; r < 8; r++) x[r] = buf_load_f2<SC1 ? AUX_SC1 : 0>(rs, l * 8, 64 * r * 8);
+}
+
+// a4..a8 for one row held in v (lane l: j = l + 64 r); returns S (the same value in every lane).
+// tw: LDS table exp(+2 pi i k / 512).
+template <bool DUMP, int TAPS>
+__device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const float2 *tw, const MaTaps &taps, int l,
+                                             int gate, bool do_dump, const DumpPtrs &dump)
+{
+    float *fbuf = reinterpret_cast<float *>(buf);
+    asm volatile("" : "+v"(l));   // keep the per-lane LDS addresses inside the row (see range_stage12)
+    // a4: mean over the row, subtract (rpv2.cu:434-439)
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { sr += v[r].x; si += v[r].y; }
+    sr = wave_sum(sr) * (1.0f / DP_N);
+    si = wave_sum(si) * (1.0f / DP_N);
+#pragma unroll
+    for (int r = 0; r < 8; r++) { v[r].x -= sr; v[r].y -= si; }
+
+    // a5: Z[k] = sum_j (x_j - mu) exp(+2 pi i j k / n)   (= conj . FFT . conj)
+    cf t1[8], t2[8];                               // both twiddle sets in one batch of LDS reads
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        t1[k] = tw[(l * k) & (DP_N - 1)];
+        t2[k] = tw[(8 * (l & 7) * k) & (DP_N - 1)];
+    }
+    fft8<+1>(v);                                   // stage 1: lane l owns j = l + 64 r
+    buf[dp_idx(l)] = v[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) buf[dp_idx(k1 * 64 + l)] = cmul(v[k1], t1[k1]);
+    wave_lds_fence();
+    {                                              // stage 2: lane = p1 + 8 k1, positions k1*64 + p1 + 8 r
+        const int p1 = l & 7, k1 = l >> 3;
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = buf[dp_idx(k1 * 64 + p1 + 8 * r)];
+        fft8<+1>(v);
+        buf[dp_idx(k1 * 64 + p1)] = v[0];
+#pragma unroll
+        for (int k2 = 1; k2 < 8; k2++) buf[dp_idx(k1 * 64 + p1 + 8 * k2)] = cmul(v[k2], t2[k2]);
+    }
+    wave_lds_fence();
+    // stage 3: lane = k2 + 8 k1 owns positions k1*64 + k2*8 + r; output k = k1 + 8 k2 + 64 k3
+    const int k2 = l & 7, k1 = l >> 3;
+    const int klo = k1 + 8 * k2;
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = buf[dp_idx(k1 * 64 + k2 * 8 + r)];
+    fft8<+1>(v);
+    wave_lds_fence();   // everyone has read before the buffer is reused for |.|^2
+
+    if (DUMP && do_dump && dump.noshift) {   // reference dumps the FFT output before the final conj
+#pragma unroll
+        for (int k3 = 0; k3 < 8; k3++)
+            dump.noshift[(size_t)gate * DP_N + klo + 64 * k3] = make_float2(v[k3].x, -v[k3].y);
+    }
+    // shift (swap halves: j = k + n/2 mod n), clip post-shift bins n-1, n-2, |.|^2
+#pragma unroll
+    for (int k3 = 0; k3 < 8; k3++) {
+        const int j = ((k3 + 4) & 7) * 64 + klo;
+        cf z = v[k3];
+        if (j >= DP_N - 2) z = make_float2(0.f, 0.f);
+        if (DUMP && do_dump && dump.fft2) dump.fft2[(size_t)gate * DP_N + j] = z;
+        fbuf[dp_fidx(j)] = z.x * z.x + z.y * z.y;
+    }
+    wave_lds_fence();
+    // a7: P[j] = sum_t g[t] A[(j - t) mod n]; lane owns j = 8 l .. 8 l + 7 plus an 8-bin halo
+    float a[16];
+    {
+        const float4 *f4 = reinterpret_cast<const float4 *>(fbuf);
+        const int prev = 3 * ((l + 63) & 63);   // float4 index of bin 8 l - 8 (mod 512) under dp_fidx
+        const float4 h0 = f4[prev], h1 = f4[prev + 1], c0 = f4[3 * l], c1 = f4[3 * l + 1];
+        a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
+        a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
+        a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
+        a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
+    }
+    if (DUMP && do_dump && dump.abs2) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * DP_N + 8 * l + u] = a[8 + u];
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        float p = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
+        if (DUMP && do_dump && dump.pow) dump.pow[(size_t)gate * DP_N + 8 * l + u] = p;
+        part += p;
+    }
+    const float S = wave_sum(part);                // a8: row sum
+    if (DUMP && do_dump && dump.rowsum && l == 0) dump.rowsum[gate] = S;
+    wave_lds_fence();   // conv reads done before the buffer's next use
+    return S;
+}
+
+// a9: reflectivity (rpv2.cu:199-213): z = (gate*k_rr)^2 * k_cal * S_hh in double, rounded once
+__device__ __forceinline__ void reflectivity_store(float *out2, int gate, float s_hh, float s_vv, float k_rr, float k_cal)
+{
+    const double rng = (double)gate * (double)k_rr;
+    const float z = (float)(rng * rng * (double)k_cal * (double)s_hh);
+    const float zdb = 10.f * log10f(z);
+    const float zdr = 10.f * (log10f(s_hh) - log10f(s_vv));
+    *reinterpret_cast<float2 *>(out2) = make_float2(zdb, zdr);
 }
 
 template <bool DUMP, int TAPS>
@@ -214,120 +461,217 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
     int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DP_WAVES][DP_ELEMS];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float2 s_tw[DP_N];
+    const int w = wave_id(), l = threadIdx.x & 63;
     const int gate = blockIdx.x * DP_WAVES + w;
     const int sec = blockIdx.y;
-    float2 *buf = lds[w];
-    float *fbuf = reinterpret_cast<float *>(buf);
-
-    // both rows in flight before any arithmetic
-    cf x[2][8];
+    cf x[2][8];                      // both rows in flight before any arithmetic
 #pragma unroll
-    for (int ch = 0; ch < 2; ch++) {
-        const float2 *row = mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N;
-#pragma unroll
-        for (int r = 0; r < 8; r++) x[ch][r] = row[l + 64 * r];
-    }
-    // per-lane twiddles, shared by both channels
-    cf t1[8], t2[8];
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        t1[k] = tw[(l * k) & (DP_N - 1)];            // W_512^{l k}
-        t2[k] = tw[(8 * (l & 7) * k) & (DP_N - 1)];  // W_64^{p1 k}
-    }
-
+    for (int ch = 0; ch < 2; ch++)
+        doppler_load_row<false>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
+    for (int e = threadIdx.x; e < DP_N; e += DP_WAVES * 64) s_tw[e] = tw[e];
+    __syncthreads();
     float S[2];
 #pragma unroll
-    for (int ch = 0; ch < 2; ch++) {
-        cf(&v)[8] = x[ch];
-        const bool do_dump = DUMP && dump.channel == ch && sec == 0;
-        // a4: mean over the row, subtract (rpv2.cu:434-439)
-        float sr = 0.f, si = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; r++) { sr += v[r].x; si += v[r].y; }
-        sr = wave_sum(sr) * (1.0f / DP_N);
-        si = wave_sum(si) * (1.0f / DP_N);
-#pragma unroll
-        for (int r = 0; r < 8; r++) { v[r].x -= sr; v[r].y -= si; }
+    for (int ch = 0; ch < 2; ch++)
+        S[ch] = doppler_row<DUMP, TAPS>(x[ch], lds[w], s_tw, taps, l, gate, DUMP && dump.channel == ch && sec == 0, dump);
+    if (l == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal);
+}
 
-        // a5: Z[k] = sum_j (x_j - mu) exp(+2 pi i j k / n)   (= conj . FFT . conj)
-        // stage 1: lane l owns j = l + 64 r
-        fft8<+1>(v);
-        buf[dp_idx(l)] = v[0];
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) buf[dp_idx(k1 * 64 + l)] = cmul(v[k1], t1[k1]);
-        wave_lds_fence();
-        // stage 2: lane = p1 + 8 k1 owns positions k1*64 + p1 + 8 r
-        {
-            const int p1 = l & 7, k1 = l >> 3;
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = buf[dp_idx(k1 * 64 + p1 + 8 * r)];
-            fft8<+1>(v);
-            buf[dp_idx(k1 * 64 + p1)] = v[0];
-#pragma unroll
-            for (int k2 = 1; k2 < 8; k2++) buf[dp_idx(k1 * 64 + p1 + 8 * k2)] = cmul(v[k2], t2[k2]);
-        }
-        wave_lds_fence();
-        // stage 3: lane = k2 + 8 k1 owns positions k1*64 + k2*8 + r; output k = k1 + 8 k2 + 64 k3
-        const int k2 = l & 7, k1 = l >> 3;
-        const int klo = k1 + 8 * k2;
-#pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = buf[dp_idx(k1 * 64 + k2 * 8 + r)];
-        fft8<+1>(v);
-        wave_lds_fence();   // everyone has read before the buffer is reused for |.|^2
+// =============================================================================================
+// fused persistent launch: one team per XCD, intermediate resident in that XCD's L2.
+//
+// Grid = one 512-thread workgroup per CU.  At start every workgroup registers with the team of
+// the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never assumed) and the grid meets once.
+// Team e then owns sectors e, e + teams, ...; for each of a sector's two channels:
+//   A  every member transforms its range tiles (rank, rank + size, ...) and stores them with
+//      plain stores into the team's own 2 MiB mid buffer -> the lines stay in this XCD's L2;
+//   -- team barrier 1 (device-scope counter; stores drained by every wave first)
+//   B  every wave transforms its gates' rows, loading them with sc1 loads (bypass the CU's L1,
+//      which may hold the previous task's lines of the same addresses; served by the shared L2);
+//      right behind its own row loads it requests the first tile of the NEXT task (vmcnt retires
+//      in issue order, so the rows are not delayed), which lands during the Doppler arithmetic;
+//      HH row sums are parked in LDS, the VV pass finishes Zdb/Zdr;
+//   -- team barrier 2 is only waited for just before the NEXT task's stage-3 stores.
+// All spins are bounded; a timeout sets ctl->timeout and every workgroup leaves.
+// =============================================================================================
+struct FusedCtl {            // zeroed by hipMemsetAsync before every launch
+    unsigned census[8];      // workgroups per XCC
+    unsigned arrived;        // grid-wide start counter
+    unsigned timeout;        // != 0: a bounded spin gave up
+    unsigned pad[6];
+    unsigned bar1[8][16];    // one 64-byte line per team
+    unsigned bar2[8][16];
+};
+constexpr int FUSED_THREADS = 512;
+constexpr int FUSED_STAMP_TASKS = 16;
+constexpr int FUSED_HH_SLOTS = 64;                                       // gates per wave, worst case (team of one)
+constexpr int FUSED_OFF_HH = RangeTile<16>::LDS_BYTES;                   // float [8][FUSED_HH_SLOTS]
+constexpr int FUSED_OFF_CTL = FUSED_OFF_HH + 8 * FUSED_HH_SLOTS * 4;     // int [16]
+constexpr int FUSED_OFF_TWN = FUSED_OFF_CTL + 64;                        // float2 [512] exp(+2 pi i k / 512)
+constexpr int FUSED_LDS_BYTES = FUSED_OFF_TWN + DP_N * 8;                // 157760 <= 160 KiB
+static_assert(FUSED_LDS_BYTES <= 160 * 1024, "fused launch exceeds the CU's LDS");
+static_assert(8 * DP_ELEMS * 8 <= RangeTile<16>::TW_BLK0 * RangeTile<16>::BLK_BYTES,
+              "phase-B wave buffers must stay below the twiddle pads");
+constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;            // per team, one channel
 
-        if (do_dump && dump.noshift) {   // reference dumps the FFT output before the final conj
-#pragma unroll
-            for (int k3 = 0; k3 < 8; k3++)
-                dump.noshift[(size_t)gate * DP_N + klo + 64 * k3] = make_float2(v[k3].x, -v[k3].y);
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7;
+}
+
+// every thread calls; thread 0 polls (relaxed, device scope); false = timed out
+__device__ __forceinline__ bool team_wait_ge(unsigned *p, unsigned target, unsigned *tmo, volatile int *s_ok)
+{
+    if (threadIdx.x == 0) {
+        int good = 0;
+#pragma unroll 1
+        for (unsigned spins = 0; spins < (1u << 21); spins++) {
+            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(2);
         }
-        // shift (swap halves: j = k + n/2 mod n), clip post-shift bins n-1, n-2, |.|^2
-#pragma unroll
-        for (int k3 = 0; k3 < 8; k3++) {
-            const int j = ((k3 + 4) & 7) * 64 + klo;
-            cf z = v[k3];
-            if (j >= DP_N - 2) z = make_float2(0.f, 0.f);
-            if (do_dump && dump.fft2) dump.fft2[(size_t)gate * DP_N + j] = z;
-            fbuf[j] = z.x * z.x + z.y * z.y;
-        }
-        wave_lds_fence();
-        // a7: P[j] = sum_t g[t] A[(j - t) mod n]; lane owns j = 8 l .. 8 l + 7
-        float a[16];
-        {
-            const float4 *f4 = reinterpret_cast<const float4 *>(fbuf);
-            const int base = (2 * l + 126) & 127;   // float4 index of element 8 l - 8 (mod 512)
-            const float4 h0 = f4[base], h1 = f4[(base + 1) & 127], c0 = f4[2 * l], c1 = f4[2 * l + 1];
-            a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
-            a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
-            a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
-            a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
-        }
-        if (do_dump && dump.abs2) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * DP_N + 8 * l + u] = a[8 + u];
-        }
-        float part = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            float p = 0.f;
-#pragma unroll
-            for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
-            if (do_dump && dump.pow) dump.pow[(size_t)gate * DP_N + 8 * l + u] = p;
-            part += p;
-        }
-        // a8: row sum
-        S[ch] = wave_sum(part);
-        if (do_dump && dump.rowsum && l == 0) dump.rowsum[gate] = S[ch];
-        wave_lds_fence();   // conv reads done before the next channel's stage 1 writes
+        if (!good) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_ok = good;
     }
-    // a9: reflectivity (rpv2.cu:199-213): z = (gate*k_rr)^2 * k_cal * S_hh in double, rounded once
-    if (l == 0) {
-        const double rng = (double)gate * (double)k_rr;
-        const float z = (float)(rng * rng * (double)k_cal * (double)S[0]);
-        const float zdb = 10.f * log10f(z);
-        const float zdr = 10.f * (log10f(S[0]) - log10f(S[1]));
-        *reinterpret_cast<float2 *>(&out[((size_t)sec * gates + gate) * 2]) = make_float2(zdb, zdr);
+    __syncthreads();
+    const bool ok = *s_ok != 0;
+    __syncthreads();
+    return ok;
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
+    const float2 *__restrict__ iq,   // [S][C][1024][512]
+    float *__restrict__ out,         // [S][512][2]
+    float2 *mid_pool,                // [8][512][512] one channel-sized buffer per team
+    FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
+    float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // diagnostic phase stamps (100 MHz s_memrealtime); never read by the kernel itself
+#define WRP_STAMP(k)                                                                          \
+    do {                                                                                      \
+        if (stamps && threadIdx.x == 0 && q < FUSED_STAMP_TASKS)                              \
+            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    float *s_hh = reinterpret_cast<float *>(smem + FUSED_OFF_HH);
+    volatile int *s_ctl = reinterpret_cast<volatile int *>(smem + FUSED_OFF_CTL);
+    float2 *s_twn = reinterpret_cast<float2 *>(smem + FUSED_OFF_TWN);
+    const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
+    const int n = DP_N, gates = RP_M / 2, tiles = DP_N / 16;
+    const DumpPtrs nodump{};
+    s_twn[tid] = tw_n[tid];                    // 512 threads, 512 entries
+    range_tables_to_lds<16>(smem, rc);         // visible after the barriers of the team formation
+
+    // ---- team formation -----------------------------------------------------------------
+    if (tid == 0) {
+        const unsigned x = xcc_id();
+        s_ctl[1] = (int)x;
+        s_ctl[2] = (int)atomicAdd(&ctl->census[x], 1u);
+        __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (!team_wait_ge(&ctl->arrived, gridDim.x, &ctl->timeout, &s_ctl[0])) return;
+    if (tid == 0) {
+        int teams = 0, trank = 0;
+        for (int x = 0; x < 8; x++) {
+            const unsigned c = __hip_atomic_load(&ctl->census[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c) { if (x < s_ctl[1]) trank++; teams++; }
+            if (x == s_ctl[1]) s_ctl[3] = (int)c;
+        }
+        s_ctl[4] = teams;
+        s_ctl[5] = trank;
+    }
+    __syncthreads();
+    // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
+    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]), rank = __builtin_amdgcn_readfirstlane(s_ctl[2]);
+    const int size = __builtin_amdgcn_readfirstlane(s_ctl[3]), teams = __builtin_amdgcn_readfirstlane(s_ctl[4]);
+    const int trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
+    float2 *mid = mid_pool + (size_t)xcc * FUSED_MID_ELEMS;
+    unsigned *bar1 = &ctl->bar1[xcc][0], *bar2 = &ctl->bar2[xcc][0];
+    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases image blocks 0..31 (phase B only)
+
+    float4 v[16];        // one range tile of this lane; refilled during phase B for the next task
+    float2 wdv = make_float2(0.f, 0.f);
+    bool have = false;
+    if (trank < n_sectors && rank < tiles) {
+        range_load<16>(iq + (size_t)trank * channels * RP_M * (size_t)n, n, rank * 16, rc.wd, v, wdv);
+        have = true;
+    }
+    unsigned q = 0;   // channel-tasks this team has completed
+#pragma unroll 1
+    for (int sec = trank; sec < n_sectors; sec += teams) {
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ch++, q++) {
+            const float2 *src = iq + ((size_t)sec * channels + ch) * RP_M * (size_t)n;
+            // ---- A: range tiles of this member -> team mid buffer ----------------------
+#pragma unroll 1
+            for (int t = rank; t < tiles; t += size) {
+                if (!(have && t == rank)) range_load<16>(src, n, t * 16, rc.wd, v, wdv);
+                have = false;
+                WRP_STAMP(0);
+                if (stamps && threadIdx.x == 0 && q < FUSED_STAMP_TASKS)   // shader clock, for MHz = d[6] / d[0]
+                    stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * 8 + 6] = __builtin_amdgcn_s_memtime();
+                range_stage12<16, false>(smem, v, wdv, n, t * 16, false, nodump);
+                WRP_STAMP(1);
+                // the previous task's rows must all have been read before they are overwritten
+                if (t == rank && q > 0 && !team_wait_ge(bar2, q * (unsigned)size, &ctl->timeout, &s_ctl[0])) return;
+                WRP_STAMP(2);
+                range_stage3<16, false>(smem, mid, n, t * 16, false, nodump);
+                __syncthreads();   // LDS image free for the next tile / phase B
+            }
+            // every storing wave drains its stores, then one lane signals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            WRP_STAMP(3);
+            if (tid == 0) __hip_atomic_fetch_add(bar1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!team_wait_ge(bar1, (q + 1) * (unsigned)size, &ctl->timeout, &s_ctl[0])) return;
+            WRP_STAMP(4);
+            // ---- B: Doppler rows of this wave ------------------------------------------
+            const int g0 = rank * 8 + w, gstep = size * 8;
+            const int nsec = ch == 0 ? sec : sec + teams, nch = ch ^ 1;      // next channel-task
+            // No load below sits in a conditional block (see range_load): the second row falls back
+            // to the first one's address and the prefetch to a zero-record descriptor.
+            auto pair = [&](auto prefetch, int g, int slot) {
+                const bool two = g + gstep < gates;
+                cf x0[8], x1[8];
+                doppler_load_row<true>(mid + (size_t)g * n, l, x0);
+                doppler_load_row<true>(mid + (size_t)(two ? g + gstep : g) * n, l, x1);
+                if constexpr (decltype(prefetch)::value) {
+                    const bool nv = nsec < n_sectors && rank < tiles;
+                    range_load<16>(iq + ((size_t)(nv ? nsec : sec) * channels + nch) * RP_M * (size_t)n, n, rank * 16,
+                                   rc.wd, v, wdv, nv);
+                    have = nv;
+                }
+                const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g, false, nodump);
+                float s1 = 0.f;
+                if (two) s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g + gstep, false, nodump);
+                if (l == 0) {
+                    if (ch == 0) {
+                        s_hh[w * FUSED_HH_SLOTS + slot] = s0;
+                        if (two) s_hh[w * FUSED_HH_SLOTS + slot + 1] = s1;
+                    } else {
+                        reflectivity_store(&out[((size_t)sec * gates + g) * 2], g, s_hh[w * FUSED_HH_SLOTS + slot], s0,
+                                           k_rr, k_cal);
+                        if (two)
+                            reflectivity_store(&out[((size_t)sec * gates + g + gstep) * 2], g + gstep,
+                                               s_hh[w * FUSED_HH_SLOTS + slot + 1], s1, k_rr, k_cal);
+                    }
+                }
+            };
+            pair(TagTrue{}, g0, 0);
+#pragma unroll 1
+            for (int g = g0 + 2 * gstep, slot = 2; g < gates; g += 2 * gstep, slot += 2) pair(TagFalse{}, g, slot);
+            // all of this workgroup's row loads have completed (their data was consumed)
+            __syncthreads();
+            WRP_STAMP(5);
+            if (tid == 0) __hip_atomic_fetch_add(bar2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#undef WRP_STAMP
 }
 
 } // namespace wrp
