@@ -108,7 +108,16 @@ int wrp_pinned_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes);
  * [m/2][2] floats into the host result table at (elevation, sector). */
 int wrp_submit(wrp_handle h, int slot, int sector, int elevation);
 
-/* Block until the slot's last wrp_submit has completed. */
+/* Wire-format ingest.  The reference decodes a sector on the CPU
+ * (Sector::fromByteArray, sector.cpp:52-62) and scatters int16 -> float2 into p_iq
+ * (rpv2.cu:369-383, its "restructuring" milliseconds).  Here the caller copies the datagrams
+ * as received -- m*n samples of 12 bytes: hhI hhQ vvI vvQ vhI vhQ, big-endian int16 -- into the
+ * slot's pinned raw buffer (*bytes = m*n*12) and wrp_submit_raw uploads them (half the PCIe
+ * bytes of the 3-plane fp32 block) and decodes on the GPU, bit-identically, before the chain. */
+int wrp_pinned_raw_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes);
+int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation);
+
+/* Block until the slot's last wrp_submit / wrp_submit_raw has completed. */
 int wrp_wait(wrp_handle h, int slot);
 
 /* Pointer into the host result table result[sitdim(2, m/2, n_sectors, n_elevations)]

@@ -140,6 +140,27 @@ def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, sectors):
         assert np.array_equal(ef.process_host(batch[:3]), b[:3])
 
 
+def test_wire_format_ingest_is_bit_identical_to_cpu_decode(wrp, oracle):
+    """N1: raw 12 B/sample big-endian int16 upload + GPU decode == Sector::fromByteArray + the
+    int16->float2 scatter of rpv2.cu:369-383 (oracle restatement, itself pinned by the reference's
+    compiled sector.cpp) followed by the ordinary fp32 path.  Includes the int16 extremes."""
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, M * N * 12, dtype=np.uint8)
+    raw[:12] = [0x80, 0x00, 0x7F, 0xFF, 0xFF, 0xFF, 0x00, 0x01, 0x12, 0x34, 0xFF, 0xFE]
+    hh, vv, vh = oracle.sector_from_bytes(raw, M, N)
+    for channels in (2, 3):
+        planar = oracle.sector_to_planar(hh, vv, vh, M, N, copies=channels)[0]      # [C][m][n]
+        with wrp.Engine(device=0, n_slots=1, channels=channels) as e:
+            e.raw_slot_array(0)[:] = raw
+            e.submit_raw(0, 3, 1)
+            e.wait(0)
+            got = e.result(3, 1).copy()
+            want = e.process_host(planar[None])[0]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            # the decoded block itself: stage 01hamm / window == the int16 values (exactly representable)
+            assert e.lib.wrp_submit_raw(e.handle, 0, 999, 0) == -1
+
+
 def test_vh_plane_is_carried_but_ignored(wrp, sectors):
     """channels = 3 is the reference's Dimension4(n, m, 3, streams) layout; VH feeds no output."""
     with wrp.Engine(device=0, n_slots=1, channels=3) as e3, wrp.Engine(device=0, n_slots=1) as e2:

@@ -1,0 +1,67 @@
+"""CPU-only checks of the C++ host side that keeps the reference's API (Sector, Dimension3/4,
+floats, result framing) against vectors produced by the reference's own compiled code
+(tests/golden/ref_host_codecs.npz, tools/make_golden.py) and against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "weather-radar-processing_amd", "lib", "libwrp_host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    if not os.path.exists(LIB):
+        pytest.fail(f"{LIB} not built -- run `make host`")
+    lib = C.CDLL(LIB)
+    lib.wrph_frame_result.restype = C.c_size_t
+    return lib
+
+
+def test_sector_from_byte_array(host, golden):
+    z = golden("ref_host_codecs.npz")
+    sw, sa = int(z["sweeps"]), int(z["samples"])
+    hh = np.empty(2 * sw * sa, np.int16); vv = np.empty_like(hh); vh = np.empty_like(hh)
+    buf = (C.c_char * z["raw"].size).from_buffer_copy(z["raw"].tobytes())
+    sp = C.POINTER(C.c_short)
+    host.wrph_sector_from_bytes(buf, sw, sa, hh.ctypes.data_as(sp), vv.ctypes.data_as(sp), vh.ctypes.data_as(sp))
+    assert np.array_equal(hh, z["hh"]) and np.array_equal(vv, z["vv"]) and np.array_equal(vh, z["vh"])
+
+
+def test_floats_big_endian_round_trip(host, golden):
+    z = golden("ref_host_codecs.npz")
+    fl = np.ascontiguousarray(z["floats"])
+    ab = np.empty(4 * fl.size, np.uint8)
+    host.wrph_aftoab(fl.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(fl.size), ab.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert np.array_equal(ab, z["floats_be"])
+    back = np.empty_like(fl)
+    host.wrph_abtoaf(ab.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_size_t(fl.size), back.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(back.view(np.uint32), fl.view(np.uint32))
+
+
+def test_dimension_index_maps(host, golden):
+    z = golden("ref_host_codecs.npz")
+    w, h, c, d = map(int, z["dim_whcd"])
+    for dp in range(d):
+        for y in range(h):
+            for x in range(w):
+                assert host.wrph_dim3_at_depth(w, h, d, x, y, dp) == z["dim3"][dp, y, x]
+                for cp in range(c):
+                    assert host.wrph_dim4_copy_at_depth(w, h, c, d, x, y, cp, dp) == z["dim4"][dp, cp, y, x]
+    # the production layout: Dimension4(n, m, 3, streams) (rpv2.cu:734)
+    assert host.wrph_dim4_copy_at_depth(512, 1024, 3, 2, 5, 7, 1, 1) == 7 * 512 + 5 + 512 * 1024 + 512 * 1024 * 3
+
+
+def test_result_framing_matches_oracle(host, oracle):
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((512, 2)).astype(np.float32)
+    z[0, 0] = -np.inf
+    out = np.empty(4 * 512 + 4, np.uint8)
+    for which in (0, 1):
+        for with_elev in (1, 0):
+            n = host.wrph_frame_result(z.ctypes.data_as(C.POINTER(C.c_float)), 512, 0x0142, 0x0008, which, with_elev,
+                                       out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            want = oracle.frame_result(z, 0x0142, 0x0008, which, with_elevation=bool(with_elev))
+            assert n == want.size and np.array_equal(out[:n], want)

@@ -76,6 +76,9 @@ def load_library():
     lib.wrp_last_hip_error.restype = C.c_char_p
     lib.wrp_pinned_slot.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.wrp_submit.argtypes = [vp, i, i, i]
+    lib.wrp_pinned_raw_slot.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.wrp_submit_raw.argtypes = [vp, i, i, i]
+    lib.wrp_debug_fused_stamps.argtypes = [vp, vp, i, vp, vp, C.c_size_t]
     lib.wrp_wait.argtypes = [vp, i]
     lib.wrp_result.argtypes = [vp, i, i, C.POINTER(fp)]
     lib.wrp_process_device.argtypes = [vp, vp, vp, vp]
@@ -155,6 +158,16 @@ class Engine:
         self._check(self.lib.wrp_pinned_slot(self._h, slot, C.byref(p), C.byref(nbytes)), "wrp_pinned_slot")
         buf = (C.c_char * nbytes.value).from_address(p.value)
         return np.frombuffer(buf, dtype=np.complex64).reshape(self.channels, self.m, self.n)
+
+    def raw_slot_array(self, slot):
+        """numpy view [m*n*12] uint8 of the slot's pinned wire-format buffer (sector.cpp:52-62 layout)."""
+        p, nbytes = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.wrp_pinned_raw_slot(self._h, slot, C.byref(p), C.byref(nbytes)), "wrp_pinned_raw_slot")
+        buf = (C.c_char * nbytes.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8)
+
+    def submit_raw(self, slot, sector, elevation=0):
+        self._check(self.lib.wrp_submit_raw(self._h, slot, sector, elevation), "wrp_submit_raw")
 
     def submit(self, slot, sector, elevation=0):
         self._check(self.lib.wrp_submit(self._h, slot, sector, elevation), "wrp_submit")

@@ -25,6 +25,8 @@ struct Slot {
     float2 *d_iq = nullptr;   // device [C][m][n]
     float2 *d_mid = nullptr;  // device [2][m/2][n]
     float *d_out = nullptr;   // device [m/2][2]
+    unsigned char *h_raw = nullptr;   // pinned [m*n][12] wire bytes (allocated on first use)
+    unsigned char *d_raw = nullptr;
     hipEvent_t done = nullptr;
     bool busy = false;
     bool loaded = false;      // d_iq holds an uploaded sector
@@ -200,6 +202,8 @@ int destroy_impl(wrp_engine *h)
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.h_iq) (void)hipHostFree(s.h_iq);
+        if (s.h_raw) (void)hipHostFree(s.h_raw);
+        if (s.d_raw) (void)hipFree(s.d_raw);
         if (s.d_iq) (void)hipFree(s.d_iq);
         if (s.d_mid) (void)hipFree(s.d_mid);
         if (s.d_out) (void)hipFree(s.d_out);
@@ -392,6 +396,44 @@ int wrp_submit(wrp_handle h, int slot, int sector, int elevation)
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(s.d_iq, s.h_iq, sizeof(float2) * sector_elems(c), hipMemcpyHostToDevice, s.stream));
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr);
+    if (rc != WRP_OK) return rc;
+    float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
+    HIP_TRY(h, hipMemcpyAsync(dst, s.d_out, sizeof(float) * (c.m / 2) * 2, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipEventRecord(s.done, s.stream));
+    s.busy = true;
+    s.loaded = true;
+    return WRP_OK;
+}
+
+int wrp_pinned_raw_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes)
+{
+    if (!h || slot < 0 || slot >= (int)h->slots.size() || !host_ptr) return WRP_ERR_INVALID;
+    Slot &s = h->slots[slot];
+    const size_t nbytes = (size_t)h->cfg.m * h->cfg.n * 12;
+    if (!s.h_raw) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipHostMalloc(&s.h_raw, nbytes, hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc(&s.d_raw, nbytes));
+    }
+    *host_ptr = s.h_raw;
+    if (bytes) *bytes = nbytes;
+    return WRP_OK;
+}
+
+int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation)
+{
+    if (!h || slot < 0 || slot >= (int)h->slots.size() || sector < 0 || sector >= h->cfg.n_sectors ||
+        elevation < 0 || elevation >= h->cfg.n_elevations)
+        return WRP_ERR_INVALID;
+    Slot &s = h->slots[slot];
+    if (s.busy || !s.h_raw) return WRP_ERR_STATE;
+    const wrp_config &c = h->cfg;
+    const int count = c.m * c.n;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(s.d_raw, s.h_raw, (size_t)count * 12, hipMemcpyHostToDevice, s.stream));
+    hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256), dim3(256), 0, s.stream,
+                       (const unsigned *)s.d_raw, s.d_iq, count, c.channels);
     int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr);
     if (rc != WRP_OK) return rc;
     float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;

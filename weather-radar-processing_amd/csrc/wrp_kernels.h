@@ -479,6 +479,27 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 }
 
 // =============================================================================================
+// wire decode: the sector as it arrives -- 12 bytes per sample, hhI hhQ vvI vvQ
+// vhI vhQ as big-endian int16 (sector.cpp:52-62) -- to the planar fp32 block [C][m][n] that
+// read_matrix builds on the CPU (rpv2.cu:369-383).  One sample per thread: one 12-byte load,
+// `channels` coalesced 8-byte stores.  Integer -> float is exact, so this is bit-identical to
+// Sector::fromByteArray + the scatter loop.
+// =============================================================================================
+__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [count][3] dwords
+                                                    float2 *__restrict__ iq,            // [channels][count]
+                                                    int count, int channels)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const unsigned w0 = raw[3 * t], w1 = raw[3 * t + 1], w2 = raw[3 * t + 2];
+    const unsigned w[3] = {__builtin_bswap32(w0), __builtin_bswap32(w1), __builtin_bswap32(w2)};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        if (c < channels)
+            iq[(size_t)c * count + t] = make_float2((float)(short)(w[c] >> 16), (float)(short)(w[c] & 0xffffu));
+}
+
+// =============================================================================================
 // fused persistent launch: one team per XCD, intermediate resident in that XCD's L2.
 //
 // Grid = one 512-thread workgroup per CU.  At start every workgroup registers with the team of

@@ -1,0 +1,79 @@
+// radar_processor.h -- the reference's RadarProcessor (radar_processor.h:14-96), finished, on top
+// of the C ABI of include/wrp.h.  Same constructor, start() and set_comms(); the private methods
+// keep the reference's names.  Differences, all deliberate:
+//   * read_matrix does NOT decode on the CPU: the datagrams go straight into the engine's pinned
+//     wire-format slot and are decoded on the GPU (wrp_submit_raw);
+//   * perform_stage_1/2/3 are one asynchronous submit (the reference left 2 and 3 empty,
+//     radar_processor.cu:239-247);
+//   * copy_result_to_host + send_results wait for the slot's event instead of reading the result
+//     buffer unsynchronised (gpu_1fp_streamcasc.cu:695-697);
+//   * start() returns when the source ends or max_sectors is reached (the reference never returns).
+#ifndef WRP_HOST_RADAR_PROCESSOR_H
+#define WRP_HOST_RADAR_PROCESSOR_H
+#include <stddef.h>
+
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "udpbroadcast.h"
+#include "wrp.h"
+
+#define NUM_BYTES_PER_SAMPLE (3 * 2 * 2)
+
+class RadarProcessor {
+  public:
+    RadarProcessor(int num_sectors, int num_sweeps, int num_samples, int num_elevations, int num_streams);
+    ~RadarProcessor();
+    int start();
+    void set_comms(int in_port, int *out_ports, int n_out);   // UDP: in_port raw sectors, out_ports[0] Zdb, [1] Zdr
+
+    // hooks the reference does not have (tests, file replay, other transports)
+    typedef std::function<bool(char *buf, size_t bytes)> Source;   // one sector of wire bytes; false = end
+    typedef std::function<void(int which, int sector, int elevation, const unsigned char *frame, size_t bytes)> Sink;
+    void set_source(Source s) { source_ = std::move(s); }
+    void set_sink(Sink s) { sink_ = std::move(s); }
+    void set_device(int d) { device_ = d; }
+    void set_max_sectors(long n) { max_sectors_ = n; }
+    void set_frame_with_elevation(bool on) { with_elevation_ = on; }
+    long sectors_done() const { return done_; }
+    const char *last_error() const;
+
+    const int input_ary_size, input_columns, input_rows, output_ary_size, output_columns, output_rows;
+
+  private:
+    const int n_sectors, n_sweeps, n_samples, n_elevations;
+    static const int k_range_resolution = 30;
+    static constexpr float k_calibration = 1941.05f;
+    static const int ma_count = 7;
+    const int n_streams;
+    int current_sector = 0, current_elevation = 0, current_stream = 0;
+    const int o_types = 2;
+
+    wrp_handle eng_ = nullptr;
+    int device_ = 0;
+    long max_sectors_ = -1, done_ = 0;
+    bool with_elevation_ = true;
+    int status_ = 0;
+    Source source_;
+    Sink sink_;
+    std::unique_ptr<udpbroadcast::udpserver> server_;
+    std::vector<std::unique_ptr<udpbroadcast::udpclient>> clients_;
+
+    void generate_constants();
+    void prepare_arys();
+    void initialize_streams();
+    void do_process();
+    void destroy_streams();
+    void destroy_arrays();
+
+    bool read_matrix(int sector, int elevation, int stream);
+    void copy_matrix_to_device(int sector, int elevation, int stream);
+    void perform_stage_1(int stream);
+    void perform_stage_2(int stream);
+    void perform_stage_3(int stream);
+    void advance();
+    void copy_result_to_host(int sector, int elevation, int stream);
+    void send_results(int sector, int elevation);
+};
+#endif
