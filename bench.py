@@ -70,22 +70,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    ngpu = torch.cuda.device_count()
+    dev_index = local_rank % max(ngpu, 1)     # one rank per GPU; wraps only when rehearsed on a smaller box
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+    ctl_dev = dev                              # device of the control-plane tensors (barrier / MAX)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        # control plane only (barrier + MAX of the elapsed time): RCCL when every rank has its own
+        # GPU, gloo otherwise (RCCL refuses two ranks on one device)
+        if ngpu >= world:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ctl_dev = torch.device("cpu")
 
     m, n, C = 1024, 512, 2
     S = args.sectors
     cfg = dict(n_slots=1, n_sectors=1, n_elevations=1)
     if args.max_batch > 0:
         cfg["max_batch"] = args.max_batch
-    eng = wrp_amd.Engine(device=local_rank, **cfg)
+    eng = wrp_amd.Engine(device=dev_index, **cfg)
 
     # synthetic sweep: a pool of 8 distinct sectors (SURVEY §8d generator), replicated on the
     # device into S distinct 8 MiB blocks; sector index = rank*S + k so ranks see different data
@@ -114,7 +122,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
