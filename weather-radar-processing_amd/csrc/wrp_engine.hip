@@ -14,6 +14,7 @@
 
 #include "../../include/wrp.h"
 #include "wrp_kernels.h"
+#include "wrp_generic.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 
@@ -45,6 +46,7 @@ struct wrp_engine {
     float2 *d_tw_n = nullptr; // [n]  exp(+2 pi i k / n)
     wrp::MaTaps taps;
     int taps_pad = 7;
+    bool tuned = true;        // m = 1024, n = 512: tuned kernels; otherwise wrp_generic.h
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
     bool fused = false;
@@ -81,7 +83,12 @@ namespace {
         }                                                                                  \
     } while (0)
 
-bool shape_supported(int m, int n) { return m == 1024 && n == 512; }
+bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+int ilog2(int x) { int b = 0; while ((1 << b) < x) b++; return b; }
+// m = 1024, n = 512 (the 00iq.altb shape) runs the tuned kernels; every other power-of-two shape
+// up to 2048 x 1024 (e.g. config 5's 2048 x 128) runs the generic kernels of wrp_generic.h.
+bool shape_supported(int m, int n) { return is_pow2(m) && is_pow2(n) && m >= 64 && m <= 2048 && n >= 32 && n <= 1024; }
+bool shape_tuned(int m, int n) { return m == 1024 && n == 512; }
 
 // rpv2.cu:222-250 generate_hamming_coefficients, kept separable: W[i][j] = wr_c[i] * wd[j]
 void make_window(int m, int n, std::vector<float> &wr_c, std::vector<float> &wd)
@@ -128,6 +135,19 @@ void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mi
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
+    if (!h->tuned) {
+        const wrp_config &c = h->cfg;
+        const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
+        const dim3 grid(n_sectors * 2 * (c.n / wrp::GEN_TC)), block(wrp::GEN_THREADS);
+        const size_t lds = (size_t)c.m * wrp::GEN_TC * sizeof(float2);
+        if (dump)
+            hipLaunchKernelGGL(wrp::generic_range_pass<true>, grid, block, lds, st, d_iq, d_mid, rc, c.m, ilog2(c.m),
+                               c.n, c.channels, *dump);
+        else
+            hipLaunchKernelGGL(wrp::generic_range_pass<false>, grid, block, lds, st, d_iq, d_mid, rc, c.m, ilog2(c.m),
+                               c.n, c.channels, none);
+        return;
+    }
     if (h->range_tcols == 8) {
         if (dump) launch_range_t<8, true>(h, d_iq, n_sectors, d_mid, st, *dump);
         else launch_range_t<8, false>(h, d_iq, n_sectors, d_mid, st, none);
@@ -152,6 +172,19 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
+    if (!h->tuned) {
+        const wrp_config &c = h->cfg;
+        const dim3 grid(c.m / 2, n_sectors), block(64);
+        const size_t lds = (size_t)c.n * 12;
+        const wrp::DumpPtrs &d = dump ? *dump : none;
+#define WRP_GEN_DOPPLER(DUMP, TAPS)                                                                           \
+    hipLaunchKernelGGL((wrp::generic_doppler_pass<DUMP, TAPS>), grid, block, lds, st, d_mid, d_out, h->d_tw_n, \
+                       c.m / 2, c.n, ilog2(c.n), h->taps, c.k_range_resolution, c.k_calibration, d)
+        if (h->taps_pad == 7) { if (dump) WRP_GEN_DOPPLER(true, 7); else WRP_GEN_DOPPLER(false, 7); }
+        else { if (dump) WRP_GEN_DOPPLER(true, 9); else WRP_GEN_DOPPLER(false, 9); }
+#undef WRP_GEN_DOPPLER
+        return;
+    }
     if (h->taps_pad == 7) {
         if (dump) launch_doppler_t<true, 7>(h, d_mid, n_sectors, d_out, st, *dump);
         else launch_doppler_t<false, 7>(h, d_mid, n_sectors, d_out, st, none);
@@ -241,7 +274,12 @@ int create_impl(wrp_engine *h)
     // up to 144 KiB of dynamic LDS for the range pass
     // default 8 columns x 256 threads, two workgroups per CU (measured 5 % faster than 16 x 512)
     h->range_tcols = (c.flags & 0xff) == 16 ? 16 : 8;
-    h->fused = (c.flags & WRP_FLAG_FUSED) != 0;
+    h->tuned = shape_tuned(c.m, c.n);
+    h->fused = h->tuned && (c.flags & WRP_FLAG_FUSED) != 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::generic_range_pass<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * wrp::GEN_TC * 8));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::generic_range_pass<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * wrp::GEN_TC * 8));
     {
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
@@ -288,7 +326,7 @@ int create_impl(wrp_engine *h)
     // from 24 to 120); the 480 MiB workspace is 0.2 % of the 288 GB of HBM
     h->max_batch = c.max_batch > 0 ? c.max_batch : 120;
     HIP_TRY(h, hipMalloc(&h->d_mid, sizeof(float2) * mid_elems(c) * h->max_batch));
-    h->overlap = (c.flags & WRP_FLAG_OVERLAP) != 0;
+    h->overlap = h->tuned && (c.flags & WRP_FLAG_OVERLAP) != 0;
     if (h->overlap) {
         HIP_TRY(h, hipMalloc(&h->d_mid2, sizeof(float2) * mid_elems(c) * h->max_batch));
         HIP_TRY(h, hipStreamCreateWithFlags(&h->st_range, hipStreamNonBlocking));
