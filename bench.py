@@ -141,9 +141,19 @@ def main():
     c2 = wrp_amd.WrpConfig()
     eng.lib.wrp_get_config(eng.handle, c2)
     launches = -(-S // c2.max_batch)
+    # HBM traffic per launch pair from the committed rocprofv3 PMC run of this same configuration
+    # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; profiles/r01/traffic.json)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+        if tj["sectors_per_launch"] == c2.max_batch and c2.flags == 0:
+            traffic = round(tj["bytes_per_launch_pair"])
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "algorithmic_bytes_per_launch_pair": algo * min(S, c2.max_batch),
         "kernel": "range_pass_1024 + doppler_pass_512 (one launch pair per chunk)",
         "algorithmic_bytes_per_sector": algo, "sectors_per_launch": c2.max_batch,
         "avg_launch_pair_us": round(ms_total * 1e3 / (iters * launches), 2),
