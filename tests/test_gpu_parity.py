@@ -126,16 +126,22 @@ def test_batch_larger_than_workspace_chunk(wrp, sectors):
         assert e.process_host(batch[:0]).shape == (0, 512, 2)       # empty batch is a no-op
 
 
-def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, sectors):
-    """WRP_FLAG_FUSED: one persistent launch, XCD teams, intermediate in L2 -- same device functions,
-    so every bit must match the two-kernel path, for batch sizes that do and do not divide evenly
-    among the teams, and when the same engine is reused (control block re-zeroed per launch)."""
+def test_fused_launch_matches_two_kernel_path(wrp, oracle, sectors):
+    """WRP_FLAG_FUSED: one persistent launch, XCD teams, intermediate in L2.  Same Doppler code; the
+    range FFT is factored 8x16x8 instead of 16x8x8, so results agree to rounding: checked against
+    the two-kernel path AND the fp64 oracle, for batch sizes that do and do not divide evenly among
+    the teams, when the engine is reused (control block re-zeroed per launch), and run to run
+    (the fused launch itself must be deterministic bit for bit)."""
     with wrp.Engine(device=0, n_slots=1, flags=0x100) as ef, wrp.Engine(device=0, n_slots=1) as e2:
         for count in (8, 19):
             batch = np.stack([sectors[(3 * k + 1) % 3] * np.float32(1 + 0.25 * (k % 5)) for k in range(count)])
             a = ef.process_host(batch)
             b = e2.process_host(batch)
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), count
+            assert np.all(np.isneginf(a[:, 0, 0]))
+            assert np.max(np.abs(a[:, 1:] - b[:, 1:])) < 5e-5, count          # dB
+            assert np.array_equal(a.view(np.uint32), ef.process_host(batch).view(np.uint32))
+            for k in (0, count - 1):
+                check_final(a[k], oracle.sector(batch[k][0], batch[k][1], dtype=np.float64))
         # fewer than 8 sectors falls back to the two-kernel path by design
         assert np.array_equal(ef.process_host(batch[:3]), b[:3])
 

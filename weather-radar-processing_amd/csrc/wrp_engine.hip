@@ -15,6 +15,7 @@
 #include "../../include/wrp.h"
 #include "wrp_kernels.h"
 #include "wrp_generic.h"
+#include "wrp_fused.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 

@@ -110,7 +110,7 @@ struct RangeTile {
     static constexpr int OFF_WR = IMG_BYTES;                    // float wr_c[1024]
     static constexpr int LDS_BYTES = IMG_BYTES + RP_M * 4;      // 151552 / 77824
     static constexpr int TW_PER_PAD = ROW_BYTES / 8;            // twiddle entries per padding row (16 / 8)
-    static constexpr int TW_BLK0 = TCOLS == 16 ? 32 : 0;        // 16 cols: pads of blocks 32..95 (blocks 0..31
+    static constexpr int TW_BLK0 = TCOLS == 16 ? 64 : 0;        // 16 cols: pads of blocks 64..127 (blocks 0..63
                                                                 // are re-used as wave buffers by the fused launch)
     static __device__ __forceinline__ int addr(int pos, int colpair)   // byte address of a float4
     {
@@ -497,202 +497,6 @@ __global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ 
     for (int c = 0; c < 3; c++)
         if (c < channels)
             iq[(size_t)c * count + t] = make_float2((float)(short)(w[c] >> 16), (float)(short)(w[c] & 0xffffu));
-}
-
-// =============================================================================================
-// fused persistent launch: one team per XCD, intermediate resident in that XCD's L2.
-//
-// Grid = one 512-thread workgroup per CU.  At start every workgroup registers with the team of
-// the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never assumed) and the grid meets once.
-// Team e then owns sectors e, e + teams, ...; for each of a sector's two channels:
-//   A  every member transforms its range tiles (rank, rank + size, ...) and stores them with
-//      plain stores into the team's own 2 MiB mid buffer -> the lines stay in this XCD's L2;
-//   -- team barrier 1 (device-scope counter; stores drained by every wave first)
-//   B  every wave transforms its gates' rows, loading them with sc1 loads (bypass the CU's L1,
-//      which may hold the previous task's lines of the same addresses; served by the shared L2);
-//      right behind its own row loads it requests the first tile of the NEXT task (vmcnt retires
-//      in issue order, so the rows are not delayed), which lands during the Doppler arithmetic;
-//      HH row sums are parked in LDS, the VV pass finishes Zdb/Zdr;
-//   -- team barrier 2 is only waited for just before the NEXT task's stage-3 stores.
-// All spins are bounded; a timeout sets ctl->timeout and every workgroup leaves.
-// =============================================================================================
-struct FusedCtl {            // zeroed by hipMemsetAsync before every launch
-    unsigned census[8];      // workgroups per XCC
-    unsigned arrived;        // grid-wide start counter
-    unsigned timeout;        // != 0: a bounded spin gave up
-    unsigned pad[6];
-    unsigned bar1[8][16];    // one 64-byte line per team
-    unsigned bar2[8][16];
-};
-constexpr int FUSED_THREADS = 512;
-constexpr int FUSED_STAMP_TASKS = 16;
-constexpr int FUSED_HH_SLOTS = 64;                                       // gates per wave, worst case (team of one)
-constexpr int FUSED_OFF_HH = RangeTile<16>::LDS_BYTES;                   // float [8][FUSED_HH_SLOTS]
-constexpr int FUSED_OFF_CTL = FUSED_OFF_HH + 8 * FUSED_HH_SLOTS * 4;     // int [16]
-constexpr int FUSED_OFF_TWN = FUSED_OFF_CTL + 64;                        // float2 [512] exp(+2 pi i k / 512)
-constexpr int FUSED_LDS_BYTES = FUSED_OFF_TWN + DP_N * 8;                // 157760 <= 160 KiB
-static_assert(FUSED_LDS_BYTES <= 160 * 1024, "fused launch exceeds the CU's LDS");
-static_assert(8 * DP_ELEMS * 8 <= RangeTile<16>::TW_BLK0 * RangeTile<16>::BLK_BYTES,
-              "phase-B wave buffers must stay below the twiddle pads");
-constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;            // per team, one channel
-
-__device__ __forceinline__ unsigned xcc_id()
-{
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 7;
-}
-
-// every thread calls; thread 0 polls (relaxed, device scope); false = timed out
-__device__ __forceinline__ bool team_wait_ge(unsigned *p, unsigned target, unsigned *tmo, volatile int *s_ok)
-{
-    if (threadIdx.x == 0) {
-        int good = 0;
-#pragma unroll 1
-        for (unsigned spins = 0; spins < (1u << 21); spins++) {
-            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
-            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!good) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_ok = good;
-    }
-    __syncthreads();
-    const bool ok = *s_ok != 0;
-    __syncthreads();
-    return ok;
-}
-
-template <int TAPS>
-__global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
-    const float2 *__restrict__ iq,   // [S][C][1024][512]
-    float *__restrict__ out,         // [S][512][2]
-    float2 *mid_pool,                // [8][512][512] one channel-sized buffer per team
-    FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
-    float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // diagnostic phase stamps (100 MHz s_memrealtime); never read by the kernel itself
-#define WRP_STAMP(k)                                                                          \
-    do {                                                                                      \
-        if (stamps && threadIdx.x == 0 && q < FUSED_STAMP_TASKS)                              \
-            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-    float *s_hh = reinterpret_cast<float *>(smem + FUSED_OFF_HH);
-    volatile int *s_ctl = reinterpret_cast<volatile int *>(smem + FUSED_OFF_CTL);
-    float2 *s_twn = reinterpret_cast<float2 *>(smem + FUSED_OFF_TWN);
-    const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
-    const int n = DP_N, gates = RP_M / 2, tiles = DP_N / 16;
-    const DumpPtrs nodump{};
-    s_twn[tid] = tw_n[tid];                    // 512 threads, 512 entries
-    range_tables_to_lds<16>(smem, rc);         // visible after the barriers of the team formation
-
-    // ---- team formation -----------------------------------------------------------------
-    if (tid == 0) {
-        const unsigned x = xcc_id();
-        s_ctl[1] = (int)x;
-        s_ctl[2] = (int)atomicAdd(&ctl->census[x], 1u);
-        __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!team_wait_ge(&ctl->arrived, gridDim.x, &ctl->timeout, &s_ctl[0])) return;
-    if (tid == 0) {
-        int teams = 0, trank = 0;
-        for (int x = 0; x < 8; x++) {
-            const unsigned c = __hip_atomic_load(&ctl->census[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c) { if (x < s_ctl[1]) trank++; teams++; }
-            if (x == s_ctl[1]) s_ctl[3] = (int)c;
-        }
-        s_ctl[4] = teams;
-        s_ctl[5] = trank;
-    }
-    __syncthreads();
-    // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
-    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]), rank = __builtin_amdgcn_readfirstlane(s_ctl[2]);
-    const int size = __builtin_amdgcn_readfirstlane(s_ctl[3]), teams = __builtin_amdgcn_readfirstlane(s_ctl[4]);
-    const int trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
-    float2 *mid = mid_pool + (size_t)xcc * FUSED_MID_ELEMS;
-    unsigned *bar1 = &ctl->bar1[xcc][0], *bar2 = &ctl->bar2[xcc][0];
-    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases image blocks 0..31 (phase B only)
-
-    float4 v[16];        // one range tile of this lane; refilled during phase B for the next task
-    float2 wdv = make_float2(0.f, 0.f);
-    bool have = false;
-    if (trank < n_sectors && rank < tiles) {
-        range_load<16>(iq + (size_t)trank * channels * RP_M * (size_t)n, n, rank * 16, rc.wd, v, wdv);
-        have = true;
-    }
-    unsigned q = 0;   // channel-tasks this team has completed
-#pragma unroll 1
-    for (int sec = trank; sec < n_sectors; sec += teams) {
-#pragma unroll 1
-        for (int ch = 0; ch < 2; ch++, q++) {
-            const float2 *src = iq + ((size_t)sec * channels + ch) * RP_M * (size_t)n;
-            // ---- A: range tiles of this member -> team mid buffer ----------------------
-#pragma unroll 1
-            for (int t = rank; t < tiles; t += size) {
-                if (!(have && t == rank)) range_load<16>(src, n, t * 16, rc.wd, v, wdv);
-                have = false;
-                WRP_STAMP(0);
-                if (stamps && threadIdx.x == 0 && q < FUSED_STAMP_TASKS)   // shader clock, for MHz = d[6] / d[0]
-                    stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * 8 + 6] = __builtin_amdgcn_s_memtime();
-                range_stage12<16, false>(smem, v, wdv, n, t * 16, false, nodump);
-                WRP_STAMP(1);
-                // the previous task's rows must all have been read before they are overwritten
-                if (t == rank && q > 0 && !team_wait_ge(bar2, q * (unsigned)size, &ctl->timeout, &s_ctl[0])) return;
-                WRP_STAMP(2);
-                range_stage3<16, false>(smem, mid, n, t * 16, false, nodump);
-                __syncthreads();   // LDS image free for the next tile / phase B
-            }
-            // every storing wave drains its stores, then one lane signals
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            WRP_STAMP(3);
-            if (tid == 0) __hip_atomic_fetch_add(bar1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!team_wait_ge(bar1, (q + 1) * (unsigned)size, &ctl->timeout, &s_ctl[0])) return;
-            WRP_STAMP(4);
-            // ---- B: Doppler rows of this wave ------------------------------------------
-            const int g0 = rank * 8 + w, gstep = size * 8;
-            const int nsec = ch == 0 ? sec : sec + teams, nch = ch ^ 1;      // next channel-task
-            // No load below sits in a conditional block (see range_load): the second row falls back
-            // to the first one's address and the prefetch to a zero-record descriptor.
-            auto pair = [&](auto prefetch, int g, int slot) {
-                const bool two = g + gstep < gates;
-                cf x0[8], x1[8];
-                doppler_load_row<true>(mid + (size_t)g * n, l, x0);
-                doppler_load_row<true>(mid + (size_t)(two ? g + gstep : g) * n, l, x1);
-                if constexpr (decltype(prefetch)::value) {
-                    const bool nv = nsec < n_sectors && rank < tiles;
-                    range_load<16>(iq + ((size_t)(nv ? nsec : sec) * channels + nch) * RP_M * (size_t)n, n, rank * 16,
-                                   rc.wd, v, wdv, nv);
-                    have = nv;
-                }
-                const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g, false, nodump);
-                float s1 = 0.f;
-                if (two) s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g + gstep, false, nodump);
-                if (l == 0) {
-                    if (ch == 0) {
-                        s_hh[w * FUSED_HH_SLOTS + slot] = s0;
-                        if (two) s_hh[w * FUSED_HH_SLOTS + slot + 1] = s1;
-                    } else {
-                        reflectivity_store(&out[((size_t)sec * gates + g) * 2], g, s_hh[w * FUSED_HH_SLOTS + slot], s0,
-                                           k_rr, k_cal);
-                        if (two)
-                            reflectivity_store(&out[((size_t)sec * gates + g + gstep) * 2], g + gstep,
-                                               s_hh[w * FUSED_HH_SLOTS + slot + 1], s1, k_rr, k_cal);
-                    }
-                }
-            };
-            pair(TagTrue{}, g0, 0);
-#pragma unroll 1
-            for (int g = g0 + 2 * gstep, slot = 2; g < gates; g += 2 * gstep, slot += 2) pair(TagFalse{}, g, slot);
-            // all of this workgroup's row loads have completed (their data was consumed)
-            __syncthreads();
-            WRP_STAMP(5);
-            if (tid == 0) __hip_atomic_fetch_add(bar2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#undef WRP_STAMP
 }
 
 } // namespace wrp
