@@ -1,56 +1,62 @@
-// udpbroadcast.cpp -- thin BSD-socket wrappers with the reference's behaviour
-// (udpbroadcast.cpp:15-71): client sends to INADDR_BROADCAST:port, server binds ANY:port,
-// failures throw a const char*.
+// udpbroadcast.cpp -- see udpbroadcast.h.
 #include "udpbroadcast.h"
 
-#include <arpa/inet.h>
 #include <string.h>
 #include <sys/socket.h>
-#include <sys/types.h>
 #include <unistd.h>
 
 namespace udpbroadcast {
 
-udpclient::udpclient(int port) : mPort(port)
+namespace detail {
+
+DatagramSocket::DatagramSocket() : fd_(::socket(AF_INET, SOCK_DGRAM, 0))
 {
-    sockfd = socket(AF_INET, SOCK_DGRAM, 0);
-    if (sockfd < 0) throw "error sock";
-    int on = 1;
-    setsockopt(sockfd, SOL_SOCKET, SO_BROADCAST, &on, sizeof(on));
-    memset(&servaddr, 0, sizeof(servaddr));
-    servaddr.sin_family = AF_INET;
-    servaddr.sin_port = htons((unsigned short)mPort);
-    servaddr.sin_addr.s_addr = htonl(INADDR_BROADCAST);
+    if (fd_ < 0) throw "error sock";
 }
 
-udpclient::~udpclient() { close(sockfd); }
+DatagramSocket::~DatagramSocket()
+{
+    if (fd_ >= 0) ::close(fd_);
+}
+
+sockaddr_in DatagramSocket::address(unsigned long host_order_ip, int port)
+{
+    sockaddr_in a;
+    memset(&a, 0, sizeof a);
+    a.sin_family = AF_INET;
+    a.sin_addr.s_addr = htonl((uint32_t)host_order_ip);
+    a.sin_port = htons((uint16_t)port);
+    return a;
+}
+
+}   // namespace detail
+
+udpclient::udpclient(int port) : to_(detail::DatagramSocket::address(INADDR_BROADCAST, port))
+{
+    const int enable = 1;
+    ::setsockopt(sock_.fd(), SOL_SOCKET, SO_BROADCAST, &enable, sizeof enable);
+}
+
+udpclient::~udpclient() {}
 
 int udpclient::send(const char *message, size_t length)
 {
-    return (int)sendto(sockfd, message, length, 0, (const struct sockaddr *)&servaddr, sizeof(servaddr));
+    return (int)::sendto(sock_.fd(), message, length, 0, reinterpret_cast<const sockaddr *>(&to_), sizeof to_);
 }
 
-udpserver::udpserver(int port) : mPort(port)
+udpserver::udpserver(int port)
 {
-    sockfd = socket(AF_INET, SOCK_DGRAM, 0);
-    if (sockfd < 0) throw "error sock";
-    memset(&servaddr, 0, sizeof(servaddr));
-    memset(&cliaddr, 0, sizeof(cliaddr));
-    servaddr.sin_family = AF_INET;
-    servaddr.sin_addr.s_addr = htonl(INADDR_ANY);
-    servaddr.sin_port = htons((unsigned short)mPort);
-    if (bind(sockfd, (const struct sockaddr *)&servaddr, sizeof(servaddr)) < 0) {
-        close(sockfd);
-        throw "error bind";
-    }
+    memset(&from_, 0, sizeof from_);
+    const sockaddr_in any = detail::DatagramSocket::address(INADDR_ANY, port);
+    if (::bind(sock_.fd(), reinterpret_cast<const sockaddr *>(&any), sizeof any) != 0) throw "error bind";
 }
 
-udpserver::~udpserver() { close(sockfd); }
+udpserver::~udpserver() {}
 
 int udpserver::recv(char *buffer, size_t length)
 {
-    socklen_t len = sizeof(cliaddr);
-    return (int)recvfrom(sockfd, buffer, length, MSG_WAITALL, (struct sockaddr *)&cliaddr, &len);
+    socklen_t alen = sizeof from_;
+    return (int)::recvfrom(sock_.fd(), buffer, length, MSG_WAITALL, reinterpret_cast<sockaddr *>(&from_), &alen);
 }
 
-} // namespace udpbroadcast
+}   // namespace udpbroadcast

@@ -1,33 +1,53 @@
-// udpbroadcast.h -- UDP broadcast endpoints, API-compatible with the reference
-// (udpbroadcast.h:8-30).  I/O only; not part of the accelerated path.
+// udpbroadcast.h -- datagram endpoints for the radar's ingest (port 19001) and product egress
+// (19002 Zdb, 19003 Zdr).  Transport only; nothing here is on the accelerated path.
+//
+// namespace, class names, constructors and send/recv signatures are those a caller of the
+// reference's udpbroadcast.h:8-30 uses; construction failures throw a const char* as there
+// (udpbroadcast.cpp:19,57).  Both endpoints share one RAII socket holder.
 #ifndef WRP_HOST_UDPBROADCAST_H
 #define WRP_HOST_UDPBROADCAST_H
+
 #include <netinet/in.h>
 #include <stddef.h>
 
 namespace udpbroadcast {
 
+namespace detail {
+// owns one IPv4 datagram socket; closes it on destruction; not copyable
+class DatagramSocket {
+  public:
+    DatagramSocket();                       // throws "error sock"
+    ~DatagramSocket();
+    DatagramSocket(const DatagramSocket &) = delete;
+    DatagramSocket &operator=(const DatagramSocket &) = delete;
+    int fd() const { return fd_; }
+    static sockaddr_in address(unsigned long host_order_ip, int port);
+  private:
+    int fd_;
+};
+}   // namespace detail
+
+// sends every datagram to the limited broadcast address 255.255.255.255:port
 class udpclient {
-  private:
-    int mPort;
-    int sockfd;
-    struct sockaddr_in servaddr;
   public:
-    udpclient(int);                 // throws const char* like the reference (udpbroadcast.cpp:19)
+    udpclient(int port);
     ~udpclient();
-    int send(const char *, size_t);
-};
-
-class udpserver {
+    int send(const char *message, size_t length);   // bytes sent or -1
   private:
-    int mPort;
-    int sockfd;
-    struct sockaddr_in servaddr, cliaddr;
-  public:
-    udpserver(int);
-    ~udpserver();
-    int recv(char *, size_t);
+    detail::DatagramSocket sock_;
+    sockaddr_in to_;
 };
 
-} // namespace udpbroadcast
-#endif
+// bound to 0.0.0.0:port; recv blocks until one datagram (at most `length` bytes) arrives
+class udpserver {
+  public:
+    udpserver(int port);                            // throws "error bind"
+    ~udpserver();
+    int recv(char *buffer, size_t length);          // bytes received or -1
+  private:
+    detail::DatagramSocket sock_;
+    sockaddr_in from_;
+};
+
+}   // namespace udpbroadcast
+#endif   // WRP_HOST_UDPBROADCAST_H
