@@ -62,7 +62,7 @@ typedef struct {
     float k_calibration;      /* 1941.05 (rpv2.cu:44) */
     int max_batch;    /* sectors processed per internal chunk of wrp_process_batch_device;
                          sizes the device workspace (0 = default) */
-    int flags;        /* bits 0-7: tuning, range-pass column tile (0 = default, 8 or 16);
+    int flags;        /* bits 0-7: tuning, range-pass column tile (0 = best measured, 8 or 16);
                          WRP_FLAG_FUSED: batches of >= 8 sectors run as ONE persistent launch whose
                          XCD teams keep the intermediate in L2; other bits reserved, must be 0 */
 } wrp_config;
@@ -71,6 +71,10 @@ typedef struct {
 /* batches larger than max_batch: run the range pass of chunk k+1 beside the Doppler pass of
  * chunk k on two internal streams (joined to the caller's stream by events) */
 #define WRP_FLAG_OVERLAP 0x200
+/* By default the range pass is a fixed grid that walks the tiles and requests the next tile
+ * while the current one is being transformed.  This flag selects the one-tile-per-workgroup
+ * form instead (same arithmetic, bit-identical results; kept for A/B measurements). */
+#define WRP_FLAG_ONE_TILE_PER_BLOCK 0x400
 
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
 typedef enum {

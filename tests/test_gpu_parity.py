@@ -116,6 +116,18 @@ def test_batch_entry_matches_slot_path_bit_for_bit(engine, sectors):
         assert np.array_equal(out[k].view(np.uint32), ref[s].view(np.uint32))
 
 
+def test_range_pass_forms_are_bit_identical(wrp, sectors):
+    """The default walking-grid range pass (next tile prefetched) and the one-tile-per-workgroup
+    form, with 8- and 16-column tiles, run the same device functions: identical bits."""
+    batch = np.stack([sectors[k % 3] * np.float32(1 + 0.5 * (k % 2)) for k in range(6)])
+    outs = []
+    for flags in (0, 8, 16, 0x400, 0x400 | 8, 0x400 | 16):
+        with wrp.Engine(device=0, n_slots=1, flags=flags) as e:
+            outs.append(e.process_host(batch))
+    for o in outs[1:]:
+        assert np.array_equal(o.view(np.uint32), outs[0].view(np.uint32))
+
+
 def test_batch_larger_than_workspace_chunk(wrp, sectors):
     with wrp.Engine(device=0, n_slots=1, max_batch=2) as e:
         batch = np.stack([sectors[k % 3] for k in range(5)])

@@ -40,7 +40,7 @@ def main():
     for spec in args.variants.split(";"):
         kv = dict(x.split("=") for x in spec.split(","))
         cfg = dict(n_slots=1, n_sectors=1, n_elevations=1)
-        cfg["flags"] = int(kv.get("tcols", 0)) | (0x100 if int(kv.get("fused", 0)) else 0) | (0x200 if int(kv.get("ov", 0)) else 0)
+        cfg["flags"] = int(kv.get("tcols", 0)) | (0x100 if int(kv.get("fused", 0)) else 0) | (0x200 if int(kv.get("ov", 0)) else 0) | (0x400 if int(kv.get("onetile", 0)) else 0)
         if "mb" in kv:
             cfg["max_batch"] = int(kv["mb"])
         e = wrp_amd.Engine(device=0, **cfg)

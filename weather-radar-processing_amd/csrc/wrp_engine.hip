@@ -48,6 +48,7 @@ struct wrp_engine {
     wrp::MaTaps taps;
     int taps_pad = 7;
     bool tuned = true;        // m = 1024, n = 512: tuned kernels; otherwise wrp_generic.h
+    bool persist = false;     // range pass as a fixed grid walking the tiles with prefetch
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
     bool fused = false;
@@ -147,6 +148,23 @@ void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mi
         else
             hipLaunchKernelGGL(wrp::generic_range_pass<false>, grid, block, lds, st, d_iq, d_mid, rc, c.m, ilog2(c.m),
                                c.n, c.channels, none);
+        return;
+    }
+    if (h->persist && !dump) {
+        // fixed grid, tiles walked with prefetch; a multiple of 16 blocks keeps the XCD pairing
+        const wrp_config &c = h->cfg;
+        const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
+        if (h->range_tcols == 8) {
+            typedef wrp::RangeTile<8> T;
+            const int total = n_sectors * 2 * (c.n / 8), grid = std::min(total, (2 * h->n_cus) & ~15);
+            hipLaunchKernelGGL(wrp::range_pass_1024_persistent<8>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, st, d_iq,
+                               d_mid, rc, c.n, c.channels, total);
+        } else {
+            typedef wrp::RangeTile<16> T;
+            const int total = n_sectors * 2 * (c.n / 16), grid = std::min(total, h->n_cus & ~15);
+            hipLaunchKernelGGL(wrp::range_pass_1024_persistent<16>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, st, d_iq,
+                               d_mid, rc, c.n, c.channels, total);
+        }
         return;
     }
     if (h->range_tcols == 8) {
@@ -273,10 +291,15 @@ int create_impl(wrp_engine *h)
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipSetDevice(h->device));
     // up to 144 KiB of dynamic LDS for the range pass
-    // default 8 columns x 256 threads, two workgroups per CU (measured 5 % faster than 16 x 512)
-    h->range_tcols = (c.flags & 0xff) == 16 ? 16 : 8;
+    h->range_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // default chosen below
     h->tuned = shape_tuned(c.m, c.n);
     h->fused = h->tuned && (c.flags & WRP_FLAG_FUSED) != 0;
+    h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
+    if ((c.flags & 0xff) == 0) h->range_tcols = h->persist ? 16 : 8;   // best measured tile for each form
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024_persistent<8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<8>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024_persistent<16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<16>::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::generic_range_pass<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * wrp::GEN_TC * 8));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::generic_range_pass<true>),
@@ -323,9 +346,9 @@ int create_impl(wrp_engine *h)
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(h, hipEventCreate(&h->ev0));
     HIP_TRY(h, hipEventCreate(&h->ev1));
-    // 120 sectors per launch pair: large grids amortise launch tails (measured 4.4 -> 3.8 us/sector
-    // from 24 to 120); the 480 MiB workspace is 0.2 % of the 288 GB of HBM
-    h->max_batch = c.max_batch > 0 ? c.max_batch : 120;
+    // 360 sectors (one elevation sweep) per launch pair: large grids amortise launch tails
+    // (measured 4.4 -> 3.8 -> 3.6 us/sector at 24 / 120 / 360); the 1.4 GiB workspace is 0.5 % of HBM
+    h->max_batch = c.max_batch > 0 ? c.max_batch : 360;
     HIP_TRY(h, hipMalloc(&h->d_mid, sizeof(float2) * mid_elems(c) * h->max_batch));
     h->overlap = h->tuned && (c.flags & WRP_FLAG_OVERLAP) != 0;
     if (h->overlap) {
@@ -382,7 +405,7 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_OVERLAP)) != 0 || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
+        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_OVERLAP | WRP_FLAG_ONE_TILE_PER_BLOCK)) != 0 || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
     int ndev = 0;

@@ -151,10 +151,14 @@ __device__ __forceinline__ void range_load(const float2 *src /* wave-uniform */,
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + (l % T::CP) * 2) * 4, 0);
 }
 
-// stage 1 + stage 2 (ends with the tile in LDS, positions k1*64 + p1 + 8 k2, after a barrier)
-template <int TCOLS, bool DUMP>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// stage 1 + stage 2 (ends with the tile in LDS, positions k1*64 + p1 + 8 k2, after a barrier).
+// after_stage1() runs once v has been consumed (behind the first barrier): the persistent
+// kernels use it to request the NEXT tile into v while stages 2 and 3 of this one run.
+template <int TCOLS, bool DUMP, class Hook = NoHook>
 __device__ __forceinline__ void range_stage12(unsigned char *smem, float4 (&v)[16], float2 wdv, int n, int col_base,
-                                              bool do_dump, const DumpPtrs &dump)
+                                              bool do_dump, const DumpPtrs &dump, Hook after_stage1 = Hook())
 {
     typedef RangeTile<TCOLS> T;
     const int tid = threadIdx.x;
@@ -196,6 +200,7 @@ __device__ __forceinline__ void range_stage12(unsigned char *smem, float4 (&v)[1
         }
     }
     __syncthreads();
+    after_stage1();
     const int cp = tid % T::CP, kb = tid / (T::CP * 8);
     int p1 = (tid / T::CP) & 7;
     asm volatile("" : "+v"(p1));
@@ -293,6 +298,53 @@ __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
     __syncthreads();
     range_stage12<TCOLS, DUMP>(smem, v, wdv, n, tile * TCOLS, do_dump, dump);
     range_stage3<TCOLS, DUMP>(smem, dst, n, tile * TCOLS, do_dump, dump);
+}
+
+// Persistent form of the same pass: a fixed grid (a multiple of 16 blocks, so the XCD pairing of
+// the 8-column tiles survives) walks the tiles; the NEXT tile of a workgroup is requested as soon
+// as stage 1 has consumed the registers of the current one and flies during stages 2 and 3, so a
+// CU always has HBM requests outstanding (the one-tile-per-workgroup form alternates between
+// waiting for its loads and computing).  Same device functions -> bit-identical results.
+template <int TCOLS>
+__global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024_persistent(
+    const float2 *__restrict__ iq, float2 *__restrict__ mid, RangeConsts rc, int n, int channels, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tiles = n / TCOLS;
+    const DumpPtrs nodump{};
+    auto decode = [&](int b, int &tile, int &ch, int &sec) {
+        if (TCOLS == 8) {
+            const int x = b & 15;
+            b = (b & ~15) + ((x & 7) << 1) + (x >> 3);
+        }
+        tile = b % tiles; b /= tiles;
+        ch = b % 2;       b /= 2;
+        sec = b;
+    };
+    float4 v[16];
+    float2 wdv;
+    int b = blockIdx.x, tile, ch, sec;
+    decode(b < total_tiles ? b : 0, tile, ch, sec);
+    range_load<TCOLS>(iq + ((size_t)sec * channels + ch) * RP_M * (size_t)n, n, tile * TCOLS, rc.wd, v, wdv, b < total_tiles);
+    range_tables_to_lds<TCOLS>(smem, rc);
+    __syncthreads();
+#pragma unroll 1
+    for (; b < total_tiles; b += gridDim.x) {
+        float2 *dst = mid + ((size_t)sec * 2 + ch) * (RP_M / 2) * (size_t)n;
+        const int col_base = tile * TCOLS;
+        const float2 wcur = wdv;
+        const int nb = b + gridDim.x;
+        const bool nvalid = nb < total_tiles;
+        int ntile, nch, nsec;
+        decode(nvalid ? nb : b, ntile, nch, nsec);
+        range_stage12<TCOLS, false>(smem, v, wcur, n, col_base, false, nodump, [&]() {
+            // branch-free: a zero-record descriptor drops the loads behind the last tile
+            range_load<TCOLS>(iq + ((size_t)nsec * channels + nch) * RP_M * (size_t)n, n, ntile * TCOLS, rc.wd, v, wdv, nvalid);
+        });
+        range_stage3<TCOLS, false>(smem, dst, n, col_base, false, nodump);
+        __syncthreads();   // stage 3 has read the image before the next tile's stage 1 overwrites it
+        tile = ntile; ch = nch; sec = nsec;
+    }
 }
 
 // =============================================================================================
