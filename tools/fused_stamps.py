@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Phase anatomy of the fused persistent launch (wrp_debug_fused_stamps): per channel-task and
-workgroup, microseconds spent in  A12 (stages 1-2) | wait mid free | A3 store+drain |
-team barrier | B (Doppler rows) | gap to next task (prefetch wait)."""
+"""Phase anatomy of the fused dataflow launch (wrp_debug_fused_stamps).  Every workgroup stamps
+its first 16 items: slot 0 start, 1 (A: stages 1-2 done | B: tiles of the task complete),
+2 (A: mid buffer free | B: rows transformed), 4 end, 5 = 1000*isB + task, 6 shader clock."""
 import ctypes as C
 import os
 import sys
@@ -31,23 +31,35 @@ def main():
         rc = lib.wrp_debug_fused_stamps(eng.handle, C.c_void_p(d_iq.data_ptr()), S, C.c_void_p(d_out.data_ptr()),
                                         st.ctypes.data_as(C.c_void_p), st.size)
         assert rc == 0, rc
-    ntask = min(16, 2 * (S // 8))
-    dclk = np.diff(st[:, :ntask, 6].astype(np.float64), axis=1)
-    dreal = np.diff(st[:, :ntask, 0].astype(np.float64), axis=1) / 100.0
-    print(f"shader clock during the launch: median {np.median(dclk / dreal):.0f} MHz")
+    used = st[:, :, 4] != 0
+    kind = st[:, :, 5] >= 1000
     t = st.astype(np.float64) / 100.0     # us
-    t = t[:, :ntask, :6]
-    ph = np.diff(t, axis=2)                # A12, wait2, A3, bar1, B
-    gap = t[:, 1:, 0] - t[:, :-1, 5]       # end of B -> next tile ready
-    names = ["A12 stages1-2", "wait mid free", "A3 store+drain", "team barrier", "B doppler rows"]
-    print(f"{ntask} tasks/team recorded, {ncu} workgroups; median (p10..p90) us, tasks 2.. only")
-    for k, nm in enumerate(names):
-        x = ph[:, 2:, k].ravel()
-        print(f"  {nm:16s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
-    x = gap[:, 2:].ravel()
-    print(f"  {'gap/prefetch':16s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
-    per_task = (t[:, -1, 5] - t[:, 2, 0]) / (ntask - 3 + 1e-9)
-    print(f"  per channel-task {np.median(per_task):.2f} us  -> {np.median(per_task) * 2 / 8:.2f} us/sector with 8 teams")
+    clk = np.diff(st[:, :, 6].astype(np.float64), axis=1) / np.maximum(np.diff(t[:, :, 0], axis=1), 1e-9)
+    ok = used[:, 1:] & used[:, :-1]
+    print(f"shader clock during the launch: median {np.median(clk[ok]):.0f} MHz; "
+          f"{int(used.sum())} items recorded on {ncu} workgroups ({int((used & kind).sum())} B)")
+    skip = np.arange(16)[None, :] >= 2        # steady state only
+    for nm, sel, names, d in (
+            ("A item (range tile)", used & ~kind & skip,
+             ("wait tile arrival", "stages 1-2 (+pop, prefetch issue)", "wait mid free", "stage 3", "drain + count"),
+             [t[:, :, 7] - t[:, :, 0], t[:, :, 1] - t[:, :, 7], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2], t[:, :, 4] - t[:, :, 3]]),
+            ("B item (16 rows)", used & kind & skip,
+             ("pop + wait tiles complete", "load + transform rows (wave 0)", "other waves + wait order", "publish + drain + count"),
+             [t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2], t[:, :, 4] - t[:, :, 3]])):
+        if not sel.any():
+            continue
+        tot = (t[:, :, 4] - t[:, :, 0])[sel]
+        print(f"{nm}: median {np.median(tot):.2f} us (p10 {np.percentile(tot, 10):.2f}, p90 {np.percentile(tot, 90):.2f}), n={sel.sum()}")
+        for x, n2 in zip(d, names):
+            x = x[sel]
+            print(f"    {n2:34s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
+    gap = (t[:, 1:, 0] - t[:, :-1, 4])[ok]
+    print(f"gap between items: median {np.median(gap):.2f} us")
+    last = np.where(used, t[:, :, 4], 0).max(axis=1)
+    first = np.where(used, t[:, :, 0], np.inf).min(axis=1)
+    n_items = used.sum(axis=1)
+    print(f"items per workgroup in the stamped window: {n_items.min()}..{n_items.max()}, "
+          f"us per item per workgroup: median {np.median((last - first) / np.maximum(n_items, 1)):.2f}")
     eng.close()
 
 

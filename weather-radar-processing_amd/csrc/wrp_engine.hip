@@ -54,7 +54,7 @@ struct wrp_engine {
     bool fused = false;
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
-    float2 *d_mid_pool = nullptr;   // [8][m/2][n]
+    float2 *d_mid_pool = nullptr;   // per XCD team: mid[2][m/2][n] + HH row sums
     unsigned *h_timeout = nullptr;  // pinned copy of FusedCtl::timeout after the last fused launch
     // chunk pipeline (cfg.flags & WRP_FLAG_OVERLAP): range pass of chunk k+1 beside Doppler pass of chunk k
     bool overlap = false;
@@ -314,7 +314,7 @@ int create_impl(wrp_engine *h)
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<9>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FUSED_LDS_BYTES));
     HIP_TRY(h, hipMalloc(&h->d_ctl, sizeof(wrp::FusedCtl)));
-    HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_MID_ELEMS * 8));
+    HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8));
     HIP_TRY(h, hipHostMalloc(&h->h_timeout, sizeof(unsigned), hipHostMallocDefault));
     *h->h_timeout = 0;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, false>),

@@ -1,19 +1,35 @@
-// wrp_fused.h -- fused persistent launch: one team per XCD, the 2 MiB intermediate of a
-// sector-channel stays in that XCD's L2.  1024-thread workgroups (16 waves = 4 per SIMD).
+// wrp_fused.h -- fused persistent launch: both passes in ONE launch, the 2 MiB intermediate of a
+// sector-channel stays in an XCD's L2.  Dataflow form: no team-wide lockstep.
 //
-// Grid = one workgroup per CU.  At start every workgroup registers with the team of the XCD it
-// runs on (HW_REG_XCC_ID -- placement is READ, never assumed) and the grid meets once.  Team e
-// then owns sectors e, e + teams, ...; for each of a sector's two channels:
-//   A  every member transforms its range tiles (rank, rank + size, ...) and stores them with
-//      plain stores into the team's own mid buffer -> the lines stay in this XCD's L2;
-//   -- team barrier 1 (device-scope counter; stores drained by every wave first)
-//   B  every wave transforms one gate's row, loading it with sc1 loads (bypass the CU's L1, which
-//      may hold the previous task's lines of the same addresses; served by the shared L2); right
-//      behind its own row loads it requests its share of the NEXT task's tile (vmcnt retires in
-//      issue order, so the row is not delayed), which lands during the Doppler arithmetic;
-//      HH row sums are parked in LDS, the VV pass finishes Zdb/Zdr;
-//   -- team barrier 2 is only waited for just before the NEXT task's stage-3 stores.
-// All spins are bounded; a timeout sets ctl->timeout and every workgroup leaves.
+// Grid = one 1024-thread workgroup (16 waves = 4 per SIMD) per CU.  At start every workgroup reads
+// the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never assumed), registers with that
+// XCD's team and the grid meets once.  Team e owns sectors e, e + teams, ...; a sector is two
+// channel-TASKS q = 0, 1, 2, ... and a task is 32 A-items (range tiles of 16 columns) followed by
+// 32 B-items (16 Doppler rows each, one per wave).  The team's work is the list of item GROUPS
+//        A0  A1  B0  A2  B1  A3  B2 ...  A(T-1)  B(T-2)  B(T-1)
+// and member r of a team of sz workgroups owns items r, r + sz, ... of every group (a static
+// schedule: the next item is known at once, so it can be prefetched and its dependencies polled
+// ahead of time; a shared queue was measured slower -- the pop is an exposed L2 round trip and
+// early pops reorder the items).  The tiles of task q+1 come BEFORE the rows of task q: while
+// some workgroups still finish tiles of a task, the others already transform the previous
+// task's rows, and nobody waits at a barrier.  Dependencies are per-task completion counters:
+//   B(q) items start when all 32 A(q) items have stored their tiles          (doneA[q])
+//   A(q) items store their tile when all B(q-2) items have read that buffer  (doneB[q-2];
+//        two mid buffers per team, q mod 2)
+//   B(q) items publish (HH row sums / Zdb,Zdr) when all B(q-1) items have    (doneB[q-1];
+//        one HH row-sum table per team, written by even tasks, read by odd ones)
+// Every dependency points to an EARLIER group and every workgroup walks the groups in order, so
+// the workgroup with the earliest unfinished item can always run: no cycle.  Latency hiding:
+//   * the counter an item will need is read AHEAD (one lane, the value is looked at a phase
+//     later); only if it was not yet satisfied does the workgroup fall into the polling loop;
+//   * an item's completion is signalled LATE: its stores drain while the next item's first phase
+//     computes, and the count is added at that phase's barrier -- except that a workgroup never
+//     enters a polling loop with an unsent completion (it flushes first), which keeps the
+//     no-cycle argument valid;
+//   * the next tile is requested one phase into the current item (behind a B item's own row
+//     loads), so HBM requests are always in flight.
+// All spins are bounded and a timeout is reported.  Tiles are stored with plain stores (lines
+// stay in the XCD's L2) and rows are read with sc1 loads (bypass the reader's L1).
 //
 // Range FFT for 16 waves: 1024 = 8 x 16 x 8, in-place DIF over positions p of a column:
 //   stage 1 (registers, from the prefetch): lane owns rows p0 + 128 r, r < 8, of two columns
@@ -32,26 +48,28 @@
 
 namespace wrp {
 
-struct FusedCtl {            // zeroed by hipMemsetAsync before every launch
-    unsigned census[8];      // workgroups per XCC
-    unsigned arrived;        // grid-wide start counter
-    unsigned timeout;        // != 0: a bounded spin gave up
+constexpr int FUSED_RING = 8;   // completion counters are a ring over tasks (at most 3 tasks are in flight)
+struct FusedCtl {               // zeroed by hipMemsetAsync before every launch; every counter on its own 64-byte line
+    unsigned census[8];         // workgroups per XCC
+    unsigned arrived;           // grid-wide start counter
+    unsigned timeout;           // != 0: a bounded spin gave up
     unsigned pad[6];
-    unsigned bar1[8][16];    // one 64-byte line per team
-    unsigned bar2[8][16];
+    unsigned doneA[8][FUSED_RING][16];      // tiles stored, task q -> slot q % RING, target 32 * (q / RING + 1)
+    unsigned doneB[8][FUSED_RING][16];      // row groups finished
 };
 typedef RangeTile<16> FT;
 constexpr int FUSED_THREADS = 1024;
 constexpr int FUSED_WAVES = 16;
+constexpr int FUSED_ITEMS = 32;                                            // A-items = B-items per task
 constexpr int FUSED_STAMP_TASKS = 16;
-constexpr int FUSED_HH_SLOTS = 32;                                        // gates per wave, worst case (team of one)
-constexpr int FUSED_OFF_HH = FT::LDS_BYTES;                                // float [16][FUSED_HH_SLOTS]
-constexpr int FUSED_OFF_CTL = FUSED_OFF_HH + FUSED_WAVES * FUSED_HH_SLOTS * 4;   // int [16]
+constexpr int FUSED_OFF_CTL = FT::LDS_BYTES;                               // int [16]
 constexpr int FUSED_OFF_TWN = FUSED_OFF_CTL + 64;                          // float2 [512] exp(+2 pi i k / 512)
-constexpr int FUSED_LDS_BYTES = FUSED_OFF_TWN + DP_N * 8;                  // 157760 <= 160 KiB
+constexpr int FUSED_LDS_BYTES = FUSED_OFF_TWN + DP_N * 8;                  // 155712 <= 160 KiB
 static_assert(FUSED_LDS_BYTES <= 160 * 1024, "fused launch exceeds the CU's LDS");
-static_assert(FUSED_WAVES * DP_ELEMS * 8 <= FT::TW_BLK0 * FT::BLK_BYTES, "phase-B wave buffers must stay below the twiddle pads");
-constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;              // per team, one channel
+static_assert(FUSED_WAVES * DP_ELEMS * 8 <= FT::TW_BLK0 * FT::BLK_BYTES, "row buffers must stay below the twiddle pads");
+constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;              // one channel
+// per team: two mid buffers + one HH row-sum table
+constexpr size_t FUSED_TEAM_ELEMS = 2 * FUSED_MID_ELEMS + (RP_M / 2) / 2;  // in float2 units
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -96,7 +114,9 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + (l & 7) * 2) * 4, 0);
 }
 
-__device__ __forceinline__ void fused_stage12(unsigned char *smem, float4 (&v)[8], float2 wdv)
+template <class Hook0, class Hook>
+__device__ __forceinline__ void fused_stage12(unsigned char *smem, float4 (&v)[8], float2 wdv, Hook0 before_barrier1,
+                                              Hook after_stage1)
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // every per-lane LDS address below is recomputed per call, not hoisted + spilled
@@ -123,7 +143,9 @@ __device__ __forceinline__ void fused_stage12(unsigned char *smem, float4 (&v)[8
             *reinterpret_cast<float4 *>(smem + FT::addr(k1 * 128 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
         }
     }
+    before_barrier1();
     __syncthreads();
+    after_stage1();   // v has been consumed: the next tile may be requested into it
     {   // ---- stage 2: radix 16 over positions k1*128 + p1 + 8 r, ONE column per lane
         const int col = tid & 15, k1 = tid >> 7;
         const int p1 = (tid >> 4) & 7;
@@ -163,26 +185,28 @@ __device__ __forceinline__ void fused_stage3(const unsigned char *smem, float2 *
         buf_store_f4(rd, voff + 128 * k3 * n * 8, 0, make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y));
 }
 
+// group g of a team's list -> (is_B, task q) for T tasks; see the header for the order
+__device__ __forceinline__ void fused_decode(int g, int T, bool &isB, int &q)
+{
+    if (g == 0) { isB = false; q = 0; }
+    else if (g == 2 * T - 1) { isB = true; q = T - 1; }
+    else if (g & 1) { isB = false; q = (g + 1) / 2; }
+    else { isB = true; q = g / 2 - 1; }
+}
+
 template <int TAPS>
 __global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
-    float2 *mid_pool,                // [8][512][512] one channel-sized buffer per team
+    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[2][512][512] + hh[512]
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
     float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // diagnostic phase stamps (100 MHz s_memrealtime); never read by the kernel itself
-#define WRP_STAMP(k)                                                                          \
-    do {                                                                                      \
-        if (stamps && threadIdx.x == 0 && q < FUSED_STAMP_TASKS)                              \
-            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-    float *s_hh = reinterpret_cast<float *>(smem + FUSED_OFF_HH);
     volatile int *s_ctl = reinterpret_cast<volatile int *>(smem + FUSED_OFF_CTL);
     float2 *s_twn = reinterpret_cast<float2 *>(smem + FUSED_OFF_TWN);
     const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
-    const int n = DP_N, gates = RP_M / 2, tiles = DP_N / 16;
+    const int n = DP_N, gates = RP_M / 2;
     const DumpPtrs nodump{};
     if (tid < DP_N) s_twn[tid] = tw_n[tid];
     {   // twiddle table into the image's padding, window behind the image (1024 threads, 1024 entries)
@@ -204,82 +228,160 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
         for (int x = 0; x < 8; x++) {
             const unsigned c = __hip_atomic_load(&ctl->census[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c) { if (x < s_ctl[1]) trank++; teams++; }
-            if (x == s_ctl[1]) s_ctl[3] = (int)c;
+            if (x == s_ctl[1]) s_ctl[7] = (int)c;
         }
         s_ctl[4] = teams;
         s_ctl[5] = trank;
     }
     __syncthreads();
     // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
-    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]), rank = __builtin_amdgcn_readfirstlane(s_ctl[2]);
-    const int size = __builtin_amdgcn_readfirstlane(s_ctl[3]), teams = __builtin_amdgcn_readfirstlane(s_ctl[4]);
-    const int trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
-    float2 *mid = mid_pool + (size_t)xcc * FUSED_MID_ELEMS;
-    unsigned *bar1 = &ctl->bar1[xcc][0], *bar2 = &ctl->bar2[xcc][0];
-    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases image blocks 0..63 (phase B only)
+    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    const int teams = __builtin_amdgcn_readfirstlane(s_ctl[4]), trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
+    const int T = 2 * ((n_sectors - trank + teams - 1) / teams);             // channel-tasks of this team
+    const int rank = __builtin_amdgcn_readfirstlane(s_ctl[2]), sz = __builtin_amdgcn_readfirstlane(s_ctl[7]);
+    const int groups = 2 * T;
+    float2 *team_pool = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
+    float *hh = reinterpret_cast<float *>(team_pool + 2 * FUSED_MID_ELEMS);   // [512] HH row sums of the sector in flight
+    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases image blocks 0..63 (B items only)
+    if (rank >= FUSED_ITEMS) return;   // a team larger than a group: the surplus members own no item
 
-    float4 v[8];         // this lane's share of one range tile; refilled during phase B for the next task
-    float2 wdv;
-    bool have = trank < n_sectors && rank < tiles;
-    fused_tile_load(iq + (size_t)(have ? trank : 0) * channels * RP_M * (size_t)n, n, rank * 16, rc.wd, v, wdv, have);
-    unsigned q = 0;   // channel-tasks this team has completed
-#pragma unroll 1
-    for (int sec = trank; sec < n_sectors; sec += teams) {
-#pragma unroll 1
-        for (int ch = 0; ch < 2; ch++, q++) {
-            const float2 *src = iq + ((size_t)sec * channels + ch) * RP_M * (size_t)n;
-            // ---- A: range tiles of this member -> team mid buffer ----------------------
-#pragma unroll 1
-            for (int t = rank; t < tiles; t += size) {
-                if (!(have && t == rank)) fused_tile_load(src, n, t * 16, rc.wd, v, wdv, true);
-                have = false;
-                WRP_STAMP(0);
-                if (stamps && threadIdx.x == 0 && q < FUSED_STAMP_TASKS)   // shader clock, for MHz = d[6] / d[0]
-                    stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * 8 + 6] = __builtin_amdgcn_s_memtime();
-                fused_stage12(smem, v, wdv);
-                WRP_STAMP(1);
-                // the previous task's rows must all have been read before they are overwritten
-                if (t == rank && q > 0 && !team_wait_ge(bar2, q * (unsigned)size, &ctl->timeout, &s_ctl[0])) return;
-                WRP_STAMP(2);
-                fused_stage3(smem, mid, n, t * 16);
-                __syncthreads();   // LDS image free for the next tile / phase B
-            }
-            // every storing wave drains its stores, then one lane signals
+    auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
+    auto counter = [&](unsigned (*arr)[FUSED_RING][16], int q) { return &arr[xcc][q % FUSED_RING][0]; };
+    auto target = [&](int q) { return (unsigned)(FUSED_ITEMS * (q / FUSED_RING + 1)); };
+    auto peek = [&](unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+    unsigned *pend = nullptr;   // completion counter of the previous item: its stores are still draining
+    // stores drained by every wave, then one lane counts.  Call sites sit where the drain is free
+    // (a phase of compute after the stores) or in front of a polling loop.
+    auto flush = [&]() {
+        if (pend) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            WRP_STAMP(3);
-            if (tid == 0) __hip_atomic_fetch_add(bar1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!team_wait_ge(bar1, (q + 1) * (unsigned)size, &ctl->timeout, &s_ctl[0])) return;
-            WRP_STAMP(4);
-            // ---- B: Doppler rows, one per wave per round ---------------------------------
-            const int g0 = rank * FUSED_WAVES + w, gstep = size * FUSED_WAVES;
-            const int nsec = ch == 0 ? sec : sec + teams, nch = ch ^ 1;      // next channel-task
-            // No load below sits in a conditional block (see range_load).
-            auto row = [&](auto prefetch, int g, int slot) {
-                cf x[8];
-                doppler_load_row<true>(mid + (size_t)g * n, l, x);
-                if constexpr (decltype(prefetch)::value) {
-                    const bool nv = nsec < n_sectors && rank < tiles;
-                    fused_tile_load(iq + ((size_t)(nv ? nsec : sec) * channels + nch) * RP_M * (size_t)n, n, rank * 16,
-                                    rc.wd, v, wdv, nv);
-                    have = nv;
-                }
-                const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, g, false, nodump);
-                if (l == 0) {
-                    if (ch == 0) s_hh[w * FUSED_HH_SLOTS + slot] = s;
-                    else reflectivity_store(&out[((size_t)sec * gates + g) * 2], g, s_hh[w * FUSED_HH_SLOTS + slot], s, k_rr, k_cal);
-                }
-            };
-            row(TagTrue{}, g0, 0);
-#pragma unroll 1
-            for (int g = g0 + gstep, slot = 1; g < gates; g += gstep, slot++) row(TagFalse{}, g, slot);
-            // all of this workgroup's row loads have completed (their data was consumed)
-            __syncthreads();
-            WRP_STAMP(5);
-            if (tid == 0) __hip_atomic_fetch_add(bar2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend = nullptr;
         }
+    };
+    int chk = 0;
+    // dependency `*p >= tgt`, whose value lane 0 read a phase ago (`early`): one barrier when it was
+    // already satisfied, otherwise flush the unsent completion and poll
+    auto resolve = [&](unsigned early, unsigned *p, unsigned tgt) -> bool {
+        volatile int *slot = s_ctl + 8 + (chk++ & 3);
+        if (tid == 0) *slot = early >= tgt;
+        __syncthreads();
+        if (*slot) return true;
+        flush();
+        return team_wait_ge(p, tgt, &ctl->timeout, &s_ctl[0]);
+    };
+
+    float4 v[8];         // this lane's share of one range tile (current A item or the prefetched next one)
+    float2 wdv;
+    bool have = false;   // v holds the tile of the item about to be processed
+    unsigned dep1_early = 0;   // lane 0: the next item's first dependency, read ahead
+    int g = 0, j = rank;
+    int item_no = 0;
+#pragma unroll 1
+    while (g < groups) {
+        bool isB; int q;
+        fused_decode(g, T, isB, q);
+        // the item after this one (static schedule)
+        int ng = g, nj = j + sz;
+        if (nj >= FUSED_ITEMS) { ng = g + 1; nj = rank; }
+        bool nB = true; int nq = 0;
+        if (ng < groups) fused_decode(ng, T, nB, nq);
+        // request the next item's tile if it is an A item (zero-record descriptor otherwise: no branch around loads)
+        auto prefetch_next = [&]() {
+            const bool nv = ng < groups && !nB;
+            fused_tile_load(tile_src(nv ? nq : 0), n, (nv ? nj : 0) * 16, rc.wd, v, wdv, nv);
+            have = nv;
+        };
+        // read the next item's first dependency ahead of time (B items only: all tiles of its task stored)
+        auto peek_next = [&]() {
+            dep1_early = 0;
+            if (tid == 0 && ng < groups && nB) dep1_early = peek(counter(ctl->doneA, nq));
+        };
+        unsigned dep2_early = 0;
+        if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS) {
+            unsigned long long *st = stamps + ((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8;
+            st[0] = __builtin_amdgcn_s_memrealtime(); st[5] = (isB ? 1000u : 0u) + (unsigned)q; st[6] = __builtin_amdgcn_s_memtime();
+        }
+        if (!isB) {
+            // ---------------- A item: range tile j of task q -> mid[q & 1] ----------------
+            if (!have) fused_tile_load(tile_src(q), n, j * 16, rc.wd, v, wdv, true);
+            have = false;
+            const float2 wcur = wdv;
+            if (stamps) {   // diagnostics only: when did the tile arrive
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0 && item_no < FUSED_STAMP_TASKS)
+                    stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+            }
+            fused_stage12(
+                smem, v, wcur,
+                [&]() {   // before the barrier after stage 1: the previous item's stores have drained behind the compute
+                    if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                },
+                [&]() {   // after it: count the previous item, request the next tile, read this item's dependency ahead
+                    if (pend && tid == 0) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend = nullptr;
+                    prefetch_next();
+                    if (q >= 2 && tid == 0) dep2_early = peek(counter(ctl->doneB, q - 2));
+                });
+            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            // the buffer's previous rows (task q-2) must all have been read before they are overwritten
+            if (q >= 2 && !resolve(dep2_early, counter(ctl->doneB, q - 2), target(q - 2))) return;
+            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+            peek_next();
+            fused_stage3(smem, team_pool + (size_t)(q & 1) * FUSED_MID_ELEMS, n, j * 16);
+            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            pend = counter(ctl->doneA, q);   // counted once the stores have drained (see flush)
+        } else {
+            // ---------------- B item: gates 16 j .. 16 j + 15 of task q, one per wave ------
+            if (!resolve(dep1_early, counter(ctl->doneA, q), target(q))) return;
+            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            const int gate = j * FUSED_WAVES + w;
+            cf x[8];
+            doppler_load_row<true>(team_pool + (size_t)(q & 1) * FUSED_MID_ELEMS + (size_t)gate * n, l, x);
+            prefetch_next();                               // behind the row loads: they retire first
+            if (q >= 1 && tid == 0) dep2_early = peek(counter(ctl->doneB, q - 1));
+            const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
+            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+            // the previous item's stores drained a row transform ago: count it at this barrier
+            if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            volatile int *slot = s_ctl + 8 + (chk++ & 3);
+            if (tid == 0) *slot = q < 1 || dep2_early >= target(q - 1);
+            __syncthreads();
+            if (pend && tid == 0) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend = nullptr;
+            // publish in task order: the HH table is written by even tasks and read by the odd task that follows
+            if (!*slot && !team_wait_ge(counter(ctl->doneB, q - 1), target(q - 1), &ctl->timeout, &s_ctl[0])) return;
+            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            peek_next();
+            if (l == 0) {
+                if ((q & 1) == 0) {
+                    __hip_atomic_store(reinterpret_cast<unsigned *>(&hh[gate]), __builtin_bit_cast(unsigned, s), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const float shh = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<unsigned *>(&hh[gate]),
+                                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const int sec = trank + (q >> 1) * teams;
+                    reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, shh, s, k_rr, k_cal);
+                }
+            }
+            pend = counter(ctl->doneB, q);
+        }
+        if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
+            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();   // the LDS image / row buffers are free for the next item
+        g = ng;
+        j = nj;
+        item_no++;
     }
-#undef WRP_STAMP
+    flush();
 }
 
 } // namespace wrp
