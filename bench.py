@@ -93,6 +93,8 @@ def main():
     cfg = dict(n_slots=1, n_sectors=1, n_elevations=1)
     if args.max_batch > 0:
         cfg["max_batch"] = args.max_batch
+    if os.environ.get("WRP_FLAGS"):          # A/B measurements only (e.g. 0x100 = fused launch)
+        cfg["flags"] = int(os.environ["WRP_FLAGS"], 0)
     eng = wrp_amd.Engine(device=dev_index, **cfg)
 
     # synthetic sweep: a pool of 8 distinct sectors (SURVEY §8d generator), replicated on the

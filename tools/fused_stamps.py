@@ -44,8 +44,8 @@ def main():
              ("wait tile arrival", "stages 1-2 (+pop, prefetch issue)", "wait mid free", "stage 3", "drain + count"),
              [t[:, :, 7] - t[:, :, 0], t[:, :, 1] - t[:, :, 7], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2], t[:, :, 4] - t[:, :, 3]]),
             ("B item (16 rows)", used & kind & skip,
-             ("pop + wait tiles complete", "load + transform rows (wave 0)", "other waves + wait order", "publish + drain + count"),
-             [t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2], t[:, :, 4] - t[:, :, 3]])):
+             ("wait tiles complete", "load + transform rows (wave 0)", "the other 15 waves", "wait order", "publish + count"),
+             [t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 7] - t[:, :, 2], t[:, :, 3] - t[:, :, 7], t[:, :, 4] - t[:, :, 3]])):
         if not sel.any():
             continue
         tot = (t[:, :, 4] - t[:, :, 0])[sel]
@@ -53,6 +53,17 @@ def main():
         for x, n2 in zip(d, names):
             x = x[sel]
             print(f"    {n2:34s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
+    # who is slow?  per workgroup: time in its own arithmetic vs time waiting for others (items 2..)
+    own = np.where(kind, t[:, :, 2] - t[:, :, 1], (t[:, :, 1] - t[:, :, 7]) + (t[:, :, 3] - t[:, :, 2]))
+    wait = np.where(kind, (t[:, :, 1] - t[:, :, 0]) + (t[:, :, 3] - t[:, :, 2]), (t[:, :, 7] - t[:, :, 0]) + (t[:, :, 2] - t[:, :, 1]))
+    own_wg = np.where(used & skip, own, 0).sum(axis=1)
+    wait_wg = np.where(used & skip, wait, 0).sum(axis=1)
+    order = np.argsort(wait_wg)
+    print(f"per workgroup over items 2..15: own arithmetic median {np.median(own_wg):.1f} us (min {own_wg.min():.1f}, max {own_wg.max():.1f}); "
+          f"waiting median {np.median(wait_wg):.1f} us (min {wait_wg.min():.1f}, max {wait_wg.max():.1f})")
+    print("  least-waiting workgroups (the pace setters): " +
+          ", ".join(f"wg{w}: own {own_wg[w]:.1f} wait {wait_wg[w]:.1f}" for w in order[:6]))
+    np.save(os.path.join(ROOT, "gpurun_out", "stamps.npy"), st)
     gap = (t[:, 1:, 0] - t[:, :-1, 4])[ok]
     print(f"gap between items: median {np.median(gap):.2f} us")
     last = np.where(used, t[:, :, 4], 0).max(axis=1)

@@ -25,7 +25,9 @@ __device__ __forceinline__ void tables(unsigned char *smem, RangeConsts rc, cons
     __syncthreads();
 }
 
-// MODE 0: A items; 1: B items; 2: B items with a tile prefetch in flight; 3: A then B alternating
+// MODE 0: A items; 1: B items; 2: B items with a tile prefetch in flight; 3: A then B alternating;
+// 4 / 5: as 2 / 3 with every prefetch taken from a different channel of a 2 GiB input (HBM misses, as in the real launch)
+constexpr int NCH = 512;
 template <int MODE>
 __global__ __launch_bounds__(FUSED_THREADS) void k_phase(const float2 *iq, float2 *mid, float *out, RangeConsts rc,
                                                           const float2 *tw_n, MaTaps taps, int K)
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_phase(const float2 *iq, float
     if (MODE != 1) fused_tile_load(src, n, col, rc.wd, v, wdv, true);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
-        if (MODE == 0 || MODE == 3) {
+        if (MODE == 0 || MODE == 3 || MODE == 5) {
             const float2 wcur = wdv;
             fused_stage12(smem, v, wcur, [] {}, [&]() { if (MODE == 0) fused_tile_load(src, n, col, rc.wd, v, wdv, true); });
             fused_stage3(smem, mymid, n, col);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_phase(const float2 *iq, float
         if (MODE >= 1) {
             cf x[8];
             doppler_load_row<true>(myrows + (size_t)w * n, l, x);
-            if (MODE >= 2) fused_tile_load(src, n, col, rc.wd, v, wdv, true);
+            if (MODE >= 2) fused_tile_load(MODE >= 4 ? iq + (size_t)((blockIdx.x / 32 + 8 * (k + 1)) % NCH) * RP_M * n : src, n, col, rc.wd, v, wdv, true);
             const float s = doppler_row<false, 7>(x, wbuf, s_twn, taps, l, w, false, nodump);
             if (l == 0) out[blockIdx.x * 16 + w] = s;
             __syncthreads();
@@ -88,7 +90,7 @@ void run(const float2 *iq, float2 *mid, float *out, RangeConsts rc, const float2
 int main()
 {
     float2 *iq, *mid, *tw_m, *tw_n; float *out, *wr, *wd;
-    CK(hipMalloc(&iq, 8ull * RP_M * DP_N * 8)); CK(hipMalloc(&mid, 8ull * FUSED_MID_ELEMS * 8));
+    CK(hipMalloc(&iq, (size_t)NCH * RP_M * DP_N * 8)); CK(hipMemset(iq, 0, (size_t)NCH * RP_M * DP_N * 8)); CK(hipMalloc(&mid, 8ull * FUSED_MID_ELEMS * 8));
     CK(hipMalloc(&tw_m, 1024 * 8)); CK(hipMalloc(&tw_n, 512 * 8)); CK(hipMalloc(&out, 1 << 20));
     CK(hipMalloc(&wr, 1024 * 4)); CK(hipMalloc(&wd, 512 * 4));
     std::vector<float2> h(8ull * RP_M * DP_N);
@@ -107,5 +109,7 @@ int main()
     run<1>(iq, mid, out, rc, tw_n, "B: 16 rows, no prefetch");
     run<2>(iq, mid, out, rc, tw_n, "B: 16 rows, tile prefetch in flight");
     run<3>(iq, mid, out, rc, tw_n, "A then B (prefetch during B)");
+    run<4>(iq, mid, out, rc, tw_n, "B: 16 rows, HBM tile prefetch in flight");
+    run<5>(iq, mid, out, rc, tw_n, "A then B (HBM prefetch during B)");
     return 0;
 }
