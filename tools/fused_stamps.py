@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Phase anatomy of the fused dataflow launch (wrp_debug_fused_stamps).  Every workgroup stamps
-its first 16 items: slot 0 start, 1 (A: stages 1-2 done | B: tiles of the task complete),
-2 (A: mid buffer free | B: rows transformed), 4 end, 5 = 1000*isB + task, 6 shader clock."""
+"""Phase anatomy of the fused launch (wrp_debug_fused_stamps).  Every workgroup stamps its first 16
+rounds (s_memrealtime, 100 MHz): 0 round start, 1 tile arrived, 2 stages 1-2 done, 3 stage 3 done and
+all tiles of the previous task stored, 4 row in registers (wave 0), 5 row transformed (wave 0),
+6 all waves done and all rows of the previous task loaded, 7 tile stores issued."""
 import ctypes as C
 import os
 import sys
@@ -16,7 +17,7 @@ def main():
     import torch
     import wrp_amd
     from oracle import oracle as O
-    S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     dev = torch.device("cuda", 0)
     pool = np.stack([O.synthetic_sector(k) for k in range(2)])
     d_pool = torch.from_numpy(pool.view(np.float32).reshape(2, -1)).to(dev)
@@ -31,46 +32,21 @@ def main():
         rc = lib.wrp_debug_fused_stamps(eng.handle, C.c_void_p(d_iq.data_ptr()), S, C.c_void_p(d_out.data_ptr()),
                                         st.ctypes.data_as(C.c_void_p), st.size)
         assert rc == 0, rc
-    used = st[:, :, 4] != 0
-    kind = st[:, :, 5] >= 1000
-    t = st.astype(np.float64) / 100.0     # us
-    clk = np.diff(st[:, :, 6].astype(np.float64), axis=1) / np.maximum(np.diff(t[:, :, 0], axis=1), 1e-9)
-    ok = used[:, 1:] & used[:, :-1]
-    print(f"shader clock during the launch: median {np.median(clk[ok]):.0f} MHz; "
-          f"{int(used.sum())} items recorded on {ncu} workgroups ({int((used & kind).sum())} B)")
-    skip = np.arange(16)[None, :] >= 2        # steady state only
-    for nm, sel, names, d in (
-            ("A item (range tile)", used & ~kind & skip,
-             ("wait tile arrival", "stages 1-2 (+pop, prefetch issue)", "wait mid free", "stage 3", "drain + count"),
-             [t[:, :, 7] - t[:, :, 0], t[:, :, 1] - t[:, :, 7], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2], t[:, :, 4] - t[:, :, 3]]),
-            ("B item (16 rows)", used & kind & skip,
-             ("wait tiles complete", "load + transform rows (wave 0)", "the other 15 waves", "wait order", "publish + count"),
-             [t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 7] - t[:, :, 2], t[:, :, 3] - t[:, :, 7], t[:, :, 4] - t[:, :, 3]])):
-        if not sel.any():
-            continue
-        tot = (t[:, :, 4] - t[:, :, 0])[sel]
-        print(f"{nm}: median {np.median(tot):.2f} us (p10 {np.percentile(tot, 10):.2f}, p90 {np.percentile(tot, 90):.2f}), n={sel.sum()}")
-        for x, n2 in zip(d, names):
-            x = x[sel]
-            print(f"    {n2:34s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
-    # who is slow?  per workgroup: time in its own arithmetic vs time waiting for others (items 2..)
-    own = np.where(kind, t[:, :, 2] - t[:, :, 1], (t[:, :, 1] - t[:, :, 7]) + (t[:, :, 3] - t[:, :, 2]))
-    wait = np.where(kind, (t[:, :, 1] - t[:, :, 0]) + (t[:, :, 3] - t[:, :, 2]), (t[:, :, 7] - t[:, :, 0]) + (t[:, :, 2] - t[:, :, 1]))
-    own_wg = np.where(used & skip, own, 0).sum(axis=1)
-    wait_wg = np.where(used & skip, wait, 0).sum(axis=1)
-    order = np.argsort(wait_wg)
-    print(f"per workgroup over items 2..15: own arithmetic median {np.median(own_wg):.1f} us (min {own_wg.min():.1f}, max {own_wg.max():.1f}); "
-          f"waiting median {np.median(wait_wg):.1f} us (min {wait_wg.min():.1f}, max {wait_wg.max():.1f})")
-    print("  least-waiting workgroups (the pace setters): " +
-          ", ".join(f"wg{w}: own {own_wg[w]:.1f} wait {wait_wg[w]:.1f}" for w in order[:6]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "stamps.npy"), st)
-    gap = (t[:, 1:, 0] - t[:, :-1, 4])[ok]
-    print(f"gap between items: median {np.median(gap):.2f} us")
-    last = np.where(used, t[:, :, 4], 0).max(axis=1)
-    first = np.where(used, t[:, :, 0], np.inf).min(axis=1)
-    n_items = used.sum(axis=1)
-    print(f"items per workgroup in the stamped window: {n_items.min()}..{n_items.max()}, "
-          f"us per item per workgroup: median {np.median((last - first) / np.maximum(n_items, 1)):.2f}")
+    t = st.astype(np.float64) / 100.0     # us
+    rounds = min(16, 2 * (S // 8))
+    r = slice(2, rounds)                   # steady state: both halves of the round present
+    names = ["wait tile arrival", "stages 1-2 (+ count, tile request)", "stage 3 + wait tiles stored", "row load (wave 0)",
+             "row transform (wave 0)", "other waves + wait rows loaded", "tile stores issued"]
+    d = np.diff(t[:, r, :], axis=2)
+    print(f"{ncu} workgroups, rounds 2..{rounds - 1}; median (p10 .. p90) us")
+    for k, nm in enumerate(names):
+        x = d[:, :, k].ravel()
+        print(f"    {nm:36s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
+    per_round = np.diff(t[:, r, 0], axis=1).ravel()
+    print(f"round: median {np.median(per_round):.2f} us (p10 {np.percentile(per_round, 10):.2f}, p90 {np.percentile(per_round, 90):.2f})"
+          f"  -> {np.median(per_round) * 2 / 8:.2f} us/sector with 8 teams")
     eng.close()
 
 

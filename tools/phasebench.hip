@@ -51,12 +51,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_phase(const float2 *iq, float
         if (MODE == 0 || MODE == 3 || MODE == 5) {
             const float2 wcur = wdv;
             fused_stage12(smem, v, wcur, [] {}, [&]() { if (MODE == 0) fused_tile_load(src, n, col, rc.wd, v, wdv, true); });
-            fused_stage3(smem, mymid, n, col);
+            float4 o[4];
+            fused_stage3_compute(smem, o);
+            fused_stage3_store(mymid, n, col, o);
             __syncthreads();
         }
         if (MODE >= 1) {
             cf x[8];
-            doppler_load_row<true>(myrows + (size_t)w * n, l, x);
+            doppler_load_row<AUX_SC1>(myrows + (size_t)w * n, l, x);
             if (MODE >= 2) fused_tile_load(MODE >= 4 ? iq + (size_t)((blockIdx.x / 32 + 8 * (k + 1)) % NCH) * RP_M * n : src, n, col, rc.wd, v, wdv, true);
             const float s = doppler_row<false, 7>(x, wbuf, s_twn, taps, l, w, false, nodump);
             if (l == 0) out[blockIdx.x * 16 + w] = s;

@@ -1,35 +1,32 @@
 // wrp_fused.h -- fused persistent launch: both passes in ONE launch, the 2 MiB intermediate of a
-// sector-channel stays in an XCD's L2.  Dataflow form: no team-wide lockstep.
+// sector-channel stays in an XCD's L2 (ONE buffer per XCD: two of them plus the streaming input
+// were measured to thrash the 4 MiB L2 -- every row then came back over the fabric).
 //
 // Grid = one 1024-thread workgroup (16 waves = 4 per SIMD) per CU.  At start every workgroup reads
 // the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never assumed), registers with that
 // XCD's team and the grid meets once.  Team e owns sectors e, e + teams, ...; a sector is two
-// channel-TASKS q = 0, 1, 2, ... and a task is 32 A-items (range tiles of 16 columns) followed by
-// 32 B-items (16 Doppler rows each, one per wave).  The team's work is the list of item GROUPS
-//        A0  A1  B0  A2  B1  A3  B2 ...  A(T-1)  B(T-2)  B(T-1)
-// and member r of a team of sz workgroups owns items r, r + sz, ... of every group (a static
-// schedule: the next item is known at once, so it can be prefetched and its dependencies polled
-// ahead of time; a shared queue was measured slower -- the pop is an exposed L2 round trip and
-// early pops reorder the items).  The tiles of task q+1 come BEFORE the rows of task q: while
-// some workgroups still finish tiles of a task, the others already transform the previous
-// task's rows, and nobody waits at a barrier.  Dependencies are per-task completion counters:
-//   B(q) items start when all 32 A(q) items have stored their tiles          (doneA[q])
-//   A(q) items store their tile when all B(q-2) items have read that buffer  (doneB[q-2];
-//        two mid buffers per team, q mod 2)
-//   B(q) items publish (HH row sums / Zdb,Zdr) when all B(q-1) items have    (doneB[q-1];
-//        one HH row-sum table per team, written by even tasks, read by odd ones)
-// Every dependency points to an EARLIER group and every workgroup walks the groups in order, so
-// the workgroup with the earliest unfinished item can always run: no cycle.  Latency hiding:
-//   * the counter an item will need is read AHEAD (one lane, the value is looked at a phase
-//     later); only if it was not yet satisfied does the workgroup fall into the polling loop;
-//   * an item's completion is signalled LATE: its stores drain while the next item's first phase
-//     computes, and the count is added at that phase's barrier -- except that a workgroup never
-//     enters a polling loop with an unsent completion (it flushes first), which keeps the
-//     no-cycle argument valid;
-//   * the next tile is requested one phase into the current item (behind a B item's own row
-//     loads), so HBM requests are always in flight.
+// channel-TASKS q = 0, 1, 2, ...; member r < 32 of a team owns range tile r (16 columns) and the
+// 16 Doppler rows 16 r .. 16 r + 15 (one per wave) of every task.  The work is software-pipelined
+// so that neither hand-off is waited for right after it is produced.  Round t of a workgroup:
+//     S(t)   stages 1-3 of its tile of task t; the 4 output float4 per lane STAY IN REGISTERS
+//     B(t-1) its 16 rows of task t-1: needs every tile of t-1 stored      (counter `stored`,
+//            counted by the members during their S(t) -- a stage of arithmetic ago)
+//     W(t)   store the tile of task t into the team's buffer: needs every row of t-1 loaded
+//            (counter `loaded`, counted by each wave when its row has arrived -- a row transform ago)
+// Both dependencies point backwards and every workgroup walks the rounds in order, so the
+// workgroup that is furthest behind can always run: no cycle.  Latency hiding:
+//   * a counter is read by one lane while the other waves still compute, and only if it was not
+//     yet satisfied does the workgroup fall into the (bounded) polling loop;
+//   * the tile stores drain while the next round's stage 1 computes; their count is added at that
+//     stage's barrier -- except that a workgroup never polls with an unsent count (it flushes
+//     first), which keeps the no-cycle argument valid;
+//   * the next tile is requested right after stage 1 has consumed the current one, a whole round
+//     before it is needed.  Counter reads are placed BEFORE tile requests in program order: a
+//     wave's loads return in order, a counter read behind a tile would wait for HBM.
 // All spins are bounded and a timeout is reported.  Tiles are stored with plain stores (lines
-// stay in the XCD's L2) and rows are read with sc1 loads (bypass the reader's L1).
+// stay in the XCD's L2) and rows are read with sc0 loads (miss the reader's L1, hit the L2; sc1
+// loads were measured to miss the L2 too).  HH row sums
+// wait in a register for the VV task of the same gate (same wave, next round).
 //
 // Range FFT for 16 waves: 1024 = 8 x 16 x 8, in-place DIF over positions p of a column:
 //   stage 1 (registers, from the prefetch): lane owns rows p0 + 128 r, r < 8, of two columns
@@ -37,7 +34,7 @@
 //   stage 2 (LDS, one column per lane, b64): positions k1*128 + p1 + 8 r, r < 16 -> radix 16,
 //           twiddle W_128^{p1 k2}, in place
 //   stage 3 (LDS, column pair per lane, b128): positions k1*128 + k2*8 + r, r < 8 -> radix 8;
-//           gate k = k1 + 8 k2 + 128 k3, k3 < 4 stored.
+//           gate k = k1 + 8 k2 + 128 k3, k3 < 4 kept.
 // Same padded LDS image as range_pass_1024<16> (RangeTile<16>), twiddles in its padding.
 // Arithmetic differs from the two-kernel path only in the factorisation of the range FFT
 // (8x16x8 instead of 16x8x8), so results agree to rounding, not bit for bit.
@@ -48,19 +45,19 @@
 
 namespace wrp {
 
-constexpr int FUSED_RING = 8;   // completion counters are a ring over tasks (at most 3 tasks are in flight)
+constexpr int FUSED_RING = 8;   // completion counters are a ring over tasks (at most 2 tasks are in flight)
 struct FusedCtl {               // zeroed by hipMemsetAsync before every launch; every counter on its own 64-byte line
     unsigned census[8];         // workgroups per XCC
     unsigned arrived;           // grid-wide start counter
-    unsigned timeout;           // != 0: a bounded spin gave up
+    unsigned timeout;           // 1: a bounded spin gave up; 2: a team has fewer than 32 workgroups
     unsigned pad[6];
-    unsigned doneA[8][FUSED_RING][16];      // tiles stored, task q -> slot q % RING, target 32 * (q / RING + 1)
-    unsigned doneB[8][FUSED_RING][16];      // row groups finished
+    unsigned stored[8][FUSED_RING][16];     // tiles of task q stored: slot q % RING, target 32 * (q / RING + 1)
+    unsigned loaded[8][FUSED_RING][16];     // rows of task q in registers: target 512 * (q / RING + 1)
 };
 typedef RangeTile<16> FT;
 constexpr int FUSED_THREADS = 1024;
 constexpr int FUSED_WAVES = 16;
-constexpr int FUSED_ITEMS = 32;                                            // A-items = B-items per task
+constexpr int FUSED_ITEMS = 32;                                            // tiles = row groups per task = members at work
 constexpr int FUSED_STAMP_TASKS = 16;
 constexpr int FUSED_OFF_CTL = FT::LDS_BYTES;                               // int [16]
 constexpr int FUSED_OFF_TWN = FUSED_OFF_CTL + 64;                          // float2 [512] exp(+2 pi i k / 512)
@@ -68,8 +65,7 @@ constexpr int FUSED_LDS_BYTES = FUSED_OFF_TWN + DP_N * 8;                  // 15
 static_assert(FUSED_LDS_BYTES <= 160 * 1024, "fused launch exceeds the CU's LDS");
 static_assert(FUSED_WAVES * DP_ELEMS * 8 <= FT::TW_BLK0 * FT::BLK_BYTES, "row buffers must stay below the twiddle pads");
 constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;              // one channel
-// per team: two mid buffers + one HH row-sum table
-constexpr size_t FUSED_TEAM_ELEMS = 2 * FUSED_MID_ELEMS + (RP_M / 2) / 2;  // in float2 units
+constexpr size_t FUSED_TEAM_ELEMS = FUSED_MID_ELEMS;                       // per team: ONE mid buffer (float2 units)
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -78,15 +74,43 @@ __device__ __forceinline__ unsigned xcc_id()
     return v & 7;
 }
 
-// every thread calls; thread 0 polls (relaxed, device scope); false = timed out
-__device__ __forceinline__ bool team_wait_ge(unsigned *p, unsigned target, unsigned *tmo, volatile int *s_ok)
+// Team counters live in the XCD's L2 and are only ever touched by that XCD's workgroups, so they
+// need no coherence beyond it: additions are plain L2 atomics (no sc1 -- a device-scope atomic is
+// forwarded to the memory side of the fabric and costs a round trip of more than a microsecond)
+// and reads are sc0 loads (miss the L1, hit the L2).
+__device__ __forceinline__ void l2_count(unsigned *p)
+{
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned l2_peek(unsigned *p)
+{
+    // an atomic add of 0 with return: performed at the L2 like every atomic, so it can neither hit a
+    // stale line of the CU's L1 (an sc0 load does -- measured: the poll never saw the count) nor
+    // leave the XCD (an sc1 load does).  The zero is hidden from the compiler, which otherwise
+    // folds the idempotent atomic into exactly that sc0 load.
+    unsigned zero = 0;
+    asm volatile("" : "+v"(zero));
+    return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// drop the CU's L1 so that the loads behind it are served by the L2 (rows written by other CUs)
+__device__ __forceinline__ void l1_invalidate() { asm volatile("buffer_inv sc1" ::: "memory"); }
+
+// every thread calls; thread 0 polls; false = timed out.  TEAM: the counter is a team counter (see above),
+// otherwise it is shared by the whole grid and read at device scope.
+// control words in LDS: address space 3 spelled out, because hipcc does not infer it for volatile
+// accesses and would emit flat instructions with sc0 sc1 for them
+typedef __attribute__((address_space(3))) volatile int lds_word;
+
+template <bool TEAM>
+__device__ __forceinline__ bool team_wait_ge(unsigned *p, unsigned target, unsigned *tmo, lds_word *s_ok)
 {
     if (threadIdx.x == 0) {
         int good = 0;
 #pragma unroll 1
         for (unsigned spins = 0; spins < (1u << 21); spins++) {
-            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
-            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            const unsigned now = TEAM ? l2_peek(p) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (now >= target) { good = 1; break; }
+            if ((spins & 63) == 63 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             __builtin_amdgcn_s_sleep(2);
         }
         if (!good) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -110,7 +134,8 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * n * 8u : 0u);
     const int voff = (p0 * n + col_base + (l & 7) * 2) * 8;
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = buf_load_f4(rs, voff, 128 * r * n * 8);
+    // non-temporal: the input streams through the L2 once and must not push the team's buffer out of it
+    for (int r = 0; r < 8; r++) v[r] = buf_load_f4<AUX_NT>(rs, voff, 128 * r * n * 8);
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + (l & 7) * 2) * 4, 0);
 }
 
@@ -164,7 +189,8 @@ __device__ __forceinline__ void fused_stage12(unsigned char *smem, float4 (&v)[8
     __syncthreads();
 }
 
-__device__ __forceinline__ void fused_stage3(const unsigned char *smem, float2 *dst /* wave-uniform */, int n, int col_base)
+// stage 3 in two halves: the arithmetic (outputs of gates k1 + 8 k2 + 128 k3, k3 < 4, of one column pair) ...
+__device__ __forceinline__ void fused_stage3_compute(const unsigned char *smem, float4 (&o)[4])
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -178,32 +204,33 @@ __device__ __forceinline__ void fused_stage3(const unsigned char *smem, float2 *
     }
     fft8<-1>(a);
     fft8<-1>(c);
+#pragma unroll
+    for (int k3 = 0; k3 < 4; k3++) o[k3] = make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y);
+}
+
+// ... and the stores, which may happen much later
+__device__ __forceinline__ void fused_stage3_store(float2 *dst /* wave-uniform */, int n, int col_base, const float4 (&o)[4])
+{
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int cp = tid & 7, k1 = tid >> 7, k2 = (tid >> 3) & 15;
     const rsrc_t rd = make_rsrc(dst, (unsigned)(RP_M / 2) * n * 8u);
     const int voff = ((k1 + 8 * k2) * n + col_base + cp * 2) * 8;
 #pragma unroll
     for (int k3 = 0; k3 < 4; k3++)   // gates < m/2 only; row offset in the VGPR (see buf_store_f4)
-        buf_store_f4(rd, voff + 128 * k3 * n * 8, 0, make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y));
-}
-
-// group g of a team's list -> (is_B, task q) for T tasks; see the header for the order
-__device__ __forceinline__ void fused_decode(int g, int T, bool &isB, int &q)
-{
-    if (g == 0) { isB = false; q = 0; }
-    else if (g == 2 * T - 1) { isB = true; q = T - 1; }
-    else if (g & 1) { isB = false; q = (g + 1) / 2; }
-    else { isB = true; q = g / 2 - 1; }
+        buf_store_f4(rd, voff + 128 * k3 * n * 8, 0, o[k3]);
 }
 
 template <int TAPS>
 __global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
-    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[2][512][512] + hh[512]
+    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[512][512]
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
     float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    volatile int *s_ctl = reinterpret_cast<volatile int *>(smem + FUSED_OFF_CTL);
+    lds_word *s_ctl = (lds_word *)(smem + FUSED_OFF_CTL);
     float2 *s_twn = reinterpret_cast<float2 *>(smem + FUSED_OFF_TWN);
     const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
     const int n = DP_N, gates = RP_M / 2;
@@ -222,7 +249,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
         __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (!team_wait_ge(&ctl->arrived, gridDim.x, &ctl->timeout, &s_ctl[0])) return;
+    if (!team_wait_ge<false>(&ctl->arrived, gridDim.x, &ctl->timeout, &s_ctl[0])) return;
     if (tid == 0) {
         int teams = 0, trank = 0;
         for (int x = 0; x < 8; x++) {
@@ -237,155 +264,109 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_sector_1024x512(
     // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
     const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]);
     const int teams = __builtin_amdgcn_readfirstlane(s_ctl[4]), trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
-    const int T = 2 * ((n_sectors - trank + teams - 1) / teams);             // channel-tasks of this team
     const int rank = __builtin_amdgcn_readfirstlane(s_ctl[2]), sz = __builtin_amdgcn_readfirstlane(s_ctl[7]);
-    const int groups = 2 * T;
-    float2 *team_pool = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
-    float *hh = reinterpret_cast<float *>(team_pool + 2 * FUSED_MID_ELEMS);   // [512] HH row sums of the sector in flight
-    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases image blocks 0..63 (B items only)
-    if (rank >= FUSED_ITEMS) return;   // a team larger than a group: the surplus members own no item
+    const int T = 2 * ((n_sectors - trank + teams - 1) / teams);             // channel-tasks of this team
+    float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
+    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases image blocks 0..63 (rows only)
+    if (sz < FUSED_ITEMS) {            // the static schedule needs 32 members per team
+        if (tid == 0) __hip_atomic_store(&ctl->timeout, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (rank >= FUSED_ITEMS) return;   // surplus members own nothing
+    const int col0 = rank * 16, gate = rank * FUSED_WAVES + w;
 
     auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
     auto counter = [&](unsigned (*arr)[FUSED_RING][16], int q) { return &arr[xcc][q % FUSED_RING][0]; };
-    auto target = [&](int q) { return (unsigned)(FUSED_ITEMS * (q / FUSED_RING + 1)); };
-    auto peek = [&](unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto turns = [&](int q) { return (unsigned)(q / FUSED_RING + 1); };
+    auto stamp = [&](int round, int k) {
+        if (stamps && tid == 0 && round < FUSED_STAMP_TASKS)
+            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + round) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
 
-    unsigned *pend = nullptr;   // completion counter of the previous item: its stores are still draining
-    // stores drained by every wave, then one lane counts.  Call sites sit where the drain is free
-    // (a phase of compute after the stores) or in front of a polling loop.
+    unsigned *pend = nullptr;   // `stored` counter of the tile just written: its stores are still draining
+    // stores drained by every wave, then one lane counts; in front of every polling loop
     auto flush = [&]() {
         if (pend) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) l2_count(pend);
             pend = nullptr;
         }
     };
     int chk = 0;
-    // dependency `*p >= tgt`, whose value lane 0 read a phase ago (`early`): one barrier when it was
-    // already satisfied, otherwise flush the unsent completion and poll
-    auto resolve = [&](unsigned early, unsigned *p, unsigned tgt) -> bool {
-        volatile int *slot = s_ctl + 8 + (chk++ & 3);
-        if (tid == 0) *slot = early >= tgt;
+    // dependency `*p >= tgt`, of which lane 0 holds a recent value: one barrier when it was already
+    // satisfied, otherwise flush the unsent count and poll
+    auto resolve = [&](unsigned seen, unsigned *p, unsigned tgt) -> bool {
+        lds_word *slot = s_ctl + 8 + (chk++ & 3);
+        if (tid == 0) *slot = seen >= tgt;
         __syncthreads();
         if (*slot) return true;
         flush();
-        return team_wait_ge(p, tgt, &ctl->timeout, &s_ctl[0]);
+        return team_wait_ge<true>(p, tgt, &ctl->timeout, &s_ctl[0]);
     };
 
-    float4 v[8];         // this lane's share of one range tile (current A item or the prefetched next one)
+    float4 v[8];         // this lane's share of the tile of the coming round
     float2 wdv;
-    bool have = false;   // v holds the tile of the item about to be processed
-    unsigned dep1_early = 0;   // lane 0: the next item's first dependency, read ahead
-    int g = 0, j = rank;
-    int item_no = 0;
+    float s_hh = 0.f;    // HH row sum of this wave's gate, waiting for the VV task
+    fused_tile_load(tile_src(0), n, col0, rc.wd, v, wdv, T > 0);
 #pragma unroll 1
-    while (g < groups) {
-        bool isB; int q;
-        fused_decode(g, T, isB, q);
-        // the item after this one (static schedule)
-        int ng = g, nj = j + sz;
-        if (nj >= FUSED_ITEMS) { ng = g + 1; nj = rank; }
-        bool nB = true; int nq = 0;
-        if (ng < groups) fused_decode(ng, T, nB, nq);
-        // request the next item's tile if it is an A item (zero-record descriptor otherwise: no branch around loads)
-        auto prefetch_next = [&]() {
-            const bool nv = ng < groups && !nB;
-            fused_tile_load(tile_src(nv ? nq : 0), n, (nv ? nj : 0) * 16, rc.wd, v, wdv, nv);
-            have = nv;
-        };
-        // read the next item's first dependency ahead of time (B items only: all tiles of its task stored)
-        auto peek_next = [&]() {
-            dep1_early = 0;
-            if (tid == 0 && ng < groups && nB) dep1_early = peek(counter(ctl->doneA, nq));
-        };
-        unsigned dep2_early = 0;
-        if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS) {
-            unsigned long long *st = stamps + ((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8;
-            st[0] = __builtin_amdgcn_s_memrealtime(); st[5] = (isB ? 1000u : 0u) + (unsigned)q; st[6] = __builtin_amdgcn_s_memtime();
-        }
-        if (!isB) {
-            // ---------------- A item: range tile j of task q -> mid[q & 1] ----------------
-            if (!have) fused_tile_load(tile_src(q), n, j * 16, rc.wd, v, wdv, true);
-            have = false;
+    for (int t = 0; t <= T; t++) {
+        float4 o[4];
+        unsigned seen = 0;
+        stamp(t, 0);
+        if (t < T) {
+            // ---------------- S(t): this member's tile of task t, outputs kept in registers ----------------
             const float2 wcur = wdv;
             if (stamps) {   // diagnostics only: when did the tile arrive
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (tid == 0 && item_no < FUSED_STAMP_TASKS)
-                    stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+                stamp(t, 1);
             }
             fused_stage12(
                 smem, v, wcur,
-                [&]() {   // before the barrier after stage 1: the previous item's stores have drained behind the compute
+                [&]() {   // before the barrier after stage 1: the previous tile's stores have drained behind the arithmetic
                     if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 },
-                [&]() {   // after it: count the previous item, request the next tile, read this item's dependency ahead
-                    if (pend && tid == 0) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                [&]() {   // after it: count that tile, request the next one
+                    if (pend && tid == 0) l2_count(pend);
                     pend = nullptr;
-                    // the counter read goes first: a wave's loads return in order, behind the tile it would wait for HBM
-                    if (q >= 2 && tid == 0) dep2_early = peek(counter(ctl->doneB, q - 2));
-                    prefetch_next();
+                    fused_tile_load(tile_src(t + 1 < T ? t + 1 : 0), n, col0, rc.wd, v, wdv, t + 1 < T);
                 });
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-            // the buffer's previous rows (task q-2) must all have been read before they are overwritten
-            if (q >= 2 && !resolve(dep2_early, counter(ctl->doneB, q - 2), target(q - 2))) return;
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-            peek_next();
-            fused_stage3(smem, team_pool + (size_t)(q & 1) * FUSED_MID_ELEMS, n, j * 16);
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            pend = counter(ctl->doneA, q);   // counted once the stores have drained (see flush)
+            stamp(t, 2);
+            if (t >= 1 && tid == 0) seen = l2_peek(counter(ctl->stored, t - 1));   // looked at after stage 3
+            fused_stage3_compute(smem, o);
         } else {
-            // ---------------- B item: gates 16 j .. 16 j + 15 of task q, one per wave ------
-            if (!resolve(dep1_early, counter(ctl->doneA, q), target(q))) return;
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-            const int gate = j * FUSED_WAVES + w;
-            cf x[8];
-            doppler_load_row<true>(team_pool + (size_t)(q & 1) * FUSED_MID_ELEMS + (size_t)gate * n, l, x);
-            if (q >= 1 && tid == 0) dep2_early = peek(counter(ctl->doneB, q - 1));
-            // the CU's memory pipeline serves requests in order: no wave's tile request (an HBM miss) may be
-            // queued in front of another wave's row loads (L2 hits) -- measured 5 us per item otherwise
-            __syncthreads();
-            prefetch_next();
-            const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-            // the previous item's stores drained a row transform ago: count it at this barrier
-            if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            volatile int *slot = s_ctl + 8 + (chk++ & 3);
-            if (tid == 0) *slot = q < 1 || dep2_early >= target(q - 1);
-            __syncthreads();
-            if (pend && tid == 0) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pend = nullptr;
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)   // all 16 rows done
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-            // publish in task order: the HH table is written by even tasks and read by the odd task that follows
-            if (!*slot && !team_wait_ge(counter(ctl->doneB, q - 1), target(q - 1), &ctl->timeout, &s_ctl[0])) return;
-            if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-                stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            peek_next();
-            if (l == 0) {
-                if ((q & 1) == 0) {
-                    __hip_atomic_store(reinterpret_cast<unsigned *>(&hh[gate]), __builtin_bit_cast(unsigned, s), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    const float shh = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<unsigned *>(&hh[gate]),
-                                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const int sec = trank + (q >> 1) * teams;
-                    reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, shh, s, k_rr, k_cal);
-                }
-            }
-            pend = counter(ctl->doneB, q);
+            flush();   // last round: the last tile's count is still unsent
+            if (tid == 0) seen = l2_peek(counter(ctl->stored, t - 1));
         }
-        if (stamps && tid == 0 && item_no < FUSED_STAMP_TASKS)
-            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + item_no) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-        __syncthreads();   // the LDS image / row buffers are free for the next item
-        g = ng;
-        j = nj;
-        item_no++;
+        if (t >= 1) {
+            // ---------------- B(t-1): this member's 16 rows of task t-1 ----------------
+            const int q = t - 1;
+            // every tile of the task stored (also the barrier that frees the image for the row buffers)
+            if (!resolve(seen, counter(ctl->stored, q), FUSED_ITEMS * turns(q))) return;
+            stamp(t, 3);
+            cf x[8];
+            doppler_load_row<AUX_SC1>(mid + (size_t)gate * n, l, x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row is in registers: the buffer may be overwritten
+            if (l == 0) l2_count(counter(ctl->loaded, q));
+            stamp(t, 4);
+            const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
+            stamp(t, 5);
+            if ((q & 1) == 0) s_hh = s;
+            else if (l == 0) reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh, s, k_rr, k_cal);
+        } else {
+            __syncthreads();
+        }
+        if (t < T) {
+            // ---------------- W(t): store the tile; every row of task t-1 must have been loaded ----------------
+            if (t >= 1) {
+                if (tid == 0) seen = l2_peek(counter(ctl->loaded, t - 1));   // wave 0 is done first; the others still compute
+                if (!resolve(seen, counter(ctl->loaded, t - 1), FUSED_ITEMS * FUSED_WAVES * turns(t - 1))) return;
+            }
+            stamp(t, 6);
+            fused_stage3_store(mid, n, col0, o);
+            pend = counter(ctl->stored, t);
+        }
+        stamp(t, 7);
     }
     flush();
 }

@@ -50,7 +50,14 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int AUX_SC1 = 16;   // L1-bypassing access (served by the XCD's L2)
+// Cache-policy bits of the raw buffer intrinsics on gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1.
+// Measured on MI355X: an sc0 load still HITS the CU's L1 (workgroup scope; a poll on a counter
+// written by another CU never saw the update); an sc1 load (device scope) misses the L1 AND the
+// XCD's L2 and comes back over the fabric (FETCH_SIZE).  For a hand-off between CUs of one XCD
+// through its L2 use `buffer_inv sc1` + plain loads, and L2 atomics for counters (wrp_fused.h).
+constexpr int AUX_SC0 = 1;
+constexpr int AUX_NT = 2;    // non-temporal: the line is the first to leave the caches again
+constexpr int AUX_SC1 = 16;
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)   // p, bytes wave-uniform
 {
@@ -58,9 +65,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)   // 
 }
 // NB: convert whole vectors -- element-wise __builtin_bit_cast(float, u.x) on the builtin's result
 // makes hipcc (ROCm 7.2) shrink the access to a single dword.
+template <int AUX = 0>
 __device__ __forceinline__ float4 buf_load_f4(rsrc_t r, int voff, int soff)
 {
-    const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
     return make_float4(f.x, f.y, f.z, f.w);
 }
 // ALWAYS pass soff = 0 (an immediate): with an SGPR soffset hipcc (ROCm 7.2) schedules a VALU
@@ -395,12 +403,12 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // lane l takes j = l + 64 r.  SC1 = L1-bypassing loads (rows written by other CUs in this launch)
-template <bool SC1>
+template <int AUX>   // cache policy bits: 0 plain, AUX_SC0 = miss the CU's L1 and be served by the XCD's L2
 __device__ __forceinline__ void doppler_load_row(const float2 *row /* wave-uniform */, int l, cf (&x)[8])
 {
     const rsrc_t rs = make_rsrc(row, DP_N * 8u);
 #pragma unroll
-    for (int r = 0; r < 8; r++) x[r] = buf_load_f2<SC1 ? AUX_SC1 : 0>(rs, l * 8, 64 * r * 8);
+    for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX>(rs, l * 8, 64 * r * 8);
 }
 
 // a4..a8 for one row held in v (lane l: j = l + 64 r); returns S (the same value in every lane).
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
     cf x[2][8];                      // both rows in flight before any arithmetic
 #pragma unroll
     for (int ch = 0; ch < 2; ch++)
-        doppler_load_row<false>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
+        doppler_load_row<0>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
     for (int e = threadIdx.x; e < DP_N; e += DP_WAVES * 64) s_tw[e] = tw[e];
     __syncthreads();
     float S[2];
