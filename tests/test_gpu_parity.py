@@ -144,14 +144,18 @@ def test_fused_launch_matches_two_kernel_path(wrp, oracle, sectors):
     the two-kernel path AND the fp64 oracle, for batch sizes that do and do not divide evenly among
     the teams, when the engine is reused (control block re-zeroed per launch), and run to run
     (the fused launch itself must be deterministic bit for bit)."""
-    with wrp.Engine(device=0, n_slots=1, flags=0x100) as ef, wrp.Engine(device=0, n_slots=1) as e2:
-        for count in (8, 19):
+    with wrp.Engine(device=0, n_slots=1, flags=0x100) as ef, wrp.Engine(device=0, n_slots=1, flags=0x110) as ef16, \
+            wrp.Engine(device=0, n_slots=1) as e2:
+        for count in (8, 19, 50):
             batch = np.stack([sectors[(3 * k + 1) % 3] * np.float32(1 + 0.25 * (k % 5)) for k in range(count)])
             a = ef.process_host(batch)
             b = e2.process_host(batch)
             assert np.all(np.isneginf(a[:, 0, 0]))
             assert np.max(np.abs(a[:, 1:] - b[:, 1:])) < 5e-5, count          # dB
             assert np.array_equal(a.view(np.uint32), ef.process_host(batch).view(np.uint32))
+            # two 512-thread workgroups per CU (8-column tiles, default) and one 1024-thread workgroup
+            # (16-column tiles) perform the same arithmetic per element
+            assert np.array_equal(a.view(np.uint32), ef16.process_host(batch).view(np.uint32))
             for k in (0, count - 1):
                 check_final(a[k], oracle.sector(batch[k][0], batch[k][1], dtype=np.float64))
         # fewer than 8 sectors falls back to the two-kernel path by design

@@ -23,8 +23,9 @@ def main():
     d_pool = torch.from_numpy(pool.view(np.float32).reshape(2, -1)).to(dev)
     d_iq = d_pool[torch.arange(S, device=dev) % 2].contiguous()
     d_out = torch.empty((S, 512, 2), dtype=torch.float32, device=dev)
-    eng = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, flags=0x100)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    tcols = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    eng = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, flags=0x100 | tcols)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count * (2 if tcols == 8 else 1)
     st = np.zeros((ncu, 16, 8), np.uint64)
     lib = eng.lib
     lib.wrp_debug_fused_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]

@@ -14,6 +14,13 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 using namespace wrp;
+typedef FusedGeom<16> G;
+typedef G::FT FT;
+constexpr int FUSED_THREADS = G::THREADS, FUSED_LDS_BYTES = G::LDS_BYTES, FUSED_OFF_TWN = G::OFF_TWN;
+#define fused_tile_load fused_tile_load<16>
+#define fused_stage12 fused_stage12<16>
+#define fused_stage3_compute fused_stage3_compute<16>
+#define fused_stage3_store fused_stage3_store<16>
 
 __device__ __forceinline__ void tables(unsigned char *smem, RangeConsts rc, const float2 *tw_n)
 {

@@ -52,6 +52,7 @@ struct wrp_engine {
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
     bool fused = false;
+    int fused_tcols = 8;
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_mid_pool = nullptr;   // per XCD team: mid[2][m/2][n] + HH row sums
@@ -220,15 +221,14 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
-    const dim3 grid(h->n_cus), block(wrp::FUSED_THREADS);
-    if (h->taps_pad == 7)
-        hipLaunchKernelGGL((wrp::fused_sector_1024x512<7>), grid, block, wrp::FUSED_LDS_BYTES, st, d_iq, d_out,
-                           h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,
-                           c.k_range_resolution, c.k_calibration, d_stamps);
-    else
-        hipLaunchKernelGGL((wrp::fused_sector_1024x512<9>), grid, block, wrp::FUSED_LDS_BYTES, st, d_iq, d_out,
-                           h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,
-                           c.k_range_resolution, c.k_calibration, d_stamps);
+#define WRP_FUSED(TC, TAPS)                                                                                            \
+    hipLaunchKernelGGL((wrp::fused_sector_1024x512<TC, TAPS>), dim3(h->n_cus * wrp::FusedGeom<TC>::WG_PER_CU),       \
+                       dim3(wrp::FusedGeom<TC>::THREADS), wrp::FusedGeom<TC>::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, \
+                       h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps, c.k_range_resolution, c.k_calibration, \
+                       d_stamps)
+    if (h->fused_tcols == 8) { if (h->taps_pad == 7) WRP_FUSED(8, 7); else WRP_FUSED(8, 9); }
+    else { if (h->taps_pad == 7) WRP_FUSED(16, 7); else WRP_FUSED(16, 9); }
+#undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_timeout, &h->d_ctl->timeout, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return WRP_OK;
@@ -309,10 +309,15 @@ int create_impl(wrp_engine *h)
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
         h->n_cus = prop.multiProcessorCount;
     }
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<7>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FUSED_LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FUSED_LDS_BYTES));
+    h->fused_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // two 512-thread workgroups per CU unless 16 is asked for
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<8, 7>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<8>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<8, 9>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<8>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<16, 7>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<16>::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<16, 9>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<16>::LDS_BYTES));
     HIP_TRY(h, hipMalloc(&h->d_ctl, sizeof(wrp::FusedCtl)));
     HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8));
     HIP_TRY(h, hipHostMalloc(&h->h_timeout, sizeof(unsigned), hipHostMallocDefault));
@@ -687,7 +692,7 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
                            unsigned long long *host_stamps, size_t host_count)
 {
     if (!h || !d_iq || !d_out || !host_stamps || n_sectors <= 0) return WRP_ERR_INVALID;
-    const size_t count = (size_t)h->n_cus * wrp::FUSED_STAMP_TASKS * 8;
+    const size_t count = (size_t)h->n_cus * (h->fused_tcols == 8 ? 2 : 1) * wrp::FUSED_STAMP_TASKS * 8;   // per workgroup
     if (host_count < count) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long *d = nullptr;

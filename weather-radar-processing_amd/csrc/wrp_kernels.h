@@ -51,10 +51,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 // Cache-policy bits of the raw buffer intrinsics on gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1.
-// Measured on MI355X: an sc0 load still HITS the CU's L1 (workgroup scope; a poll on a counter
-// written by another CU never saw the update); an sc1 load (device scope) misses the L1 AND the
-// XCD's L2 and comes back over the fabric (FETCH_SIZE).  For a hand-off between CUs of one XCD
-// through its L2 use `buffer_inv sc1` + plain loads, and L2 atomics for counters (wrp_fused.h).
+// Measured on MI355X (tools/l2handoff.hip): an sc0 load still HITS the CU's L1 (workgroup scope; a
+// poll on a counter written by another CU never saw the update); an sc1 load (device scope) misses
+// the L1 and is served by the XCD's L2 at full speed (1.5 TB/s per XCD) -- the right load for a
+// hand-off between CUs of one XCD; `buffer_inv sc1` + plain loads works too but the invalidate
+// costs 2.4x the time; nt marks a line as the first to be evicted.
 constexpr int AUX_SC0 = 1;
 constexpr int AUX_NT = 2;    // non-temporal: the line is the first to leave the caches again
 constexpr int AUX_SC1 = 16;
@@ -74,12 +75,18 @@ __device__ __forceinline__ float4 buf_load_f4(rsrc_t r, int voff, int soff)
 // ALWAYS pass soff = 0 (an immediate): with an SGPR soffset hipcc (ROCm 7.2) schedules a VALU
 // write to the first data VGPR directly behind the 128-bit store without the wait state gfx9
 // requires, and the store then carries the new value (seen as 0.07 dB errors in isolated gates).
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store_f4(rsrc_t r, int voff, int soff, float4 f)
 {
     v4f t;
     t.x = f.x; t.y = f.y; t.z = f.z; t.w = f.w;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), r, voff, soff, AUX);
 }
+// Cache policy of the two-kernel path's streams (input tiles in, intermediate out, intermediate
+// in): every byte is touched once per kernel, so they are non-temporal -- measured 3.53 vs 3.67
+// us/sector (A/B in one session, twice).  Exception: 8-column tiles cover half a 128-byte line and
+// rely on the neighbouring tile finding the other half in the L2 (nt: 4.7 vs 2.8 us/sector).
+template <int TCOLS> struct StreamAux { static constexpr int value = TCOLS == 16 ? 2 /* AUX_NT */ : 0; };
 template <int AUX>
 __device__ __forceinline__ float2 buf_load_f2(rsrc_t r, int voff, int soff)
 {
@@ -155,7 +162,7 @@ __device__ __forceinline__ void range_load(const float2 *src /* wave-uniform */,
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * n * 8u : 0u);
     const int voff = (p0 * n + col_base + (l % T::CP) * 2) * 8;
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = buf_load_f4(rs, voff, 64 * r * n * 8);
+    for (int r = 0; r < 16; r++) v[r] = buf_load_f4<StreamAux<TCOLS>::value>(rs, voff, 64 * r * n * 8);
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + (l % T::CP) * 2) * 4, 0);
 }
 
@@ -267,7 +274,7 @@ __device__ __forceinline__ void range_stage3(const unsigned char *smem, float2 *
         const int k0 = k1 + 16 * k2;
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++)   // row offset in the VGPR, soffset 0: see buf_store_f4
-            buf_store_f4(rd, voff + (8 * it + 128 * k3) * n * 8, 0, make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y));
+            buf_store_f4<StreamAux<TCOLS>::value>(rd, voff + (8 * it + 128 * k3) * n * 8, 0, make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y));
         if (DUMP && do_dump && dump.fft1) {
 #pragma unroll
             for (int k3 = 0; k3 < 8; k3++)
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
     cf x[2][8];                      // both rows in flight before any arithmetic
 #pragma unroll
     for (int ch = 0; ch < 2; ch++)
-        doppler_load_row<0>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
+        doppler_load_row<AUX_NT>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
     for (int e = threadIdx.x; e < DP_N; e += DP_WAVES * 64) s_tw[e] = tw[e];
     __syncthreads();
     float S[2];
