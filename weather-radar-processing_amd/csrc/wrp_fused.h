@@ -155,7 +155,7 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     const int voff = (p0 * n + col_base + cp * 2) * 8;
 #pragma unroll
     // non-temporal: the input streams through the L2 once and must not push the team's buffer out of it
-    for (int r = 0; r < 8; r++) v[r] = buf_load_f4<AUX_NT>(rs, voff, 128 * r * n * 8);
+    for (int r = 0; r < 8; r++) v[r] = buf_load_f4<StreamAux<TCOLS>::value>(rs, voff, 128 * r * n * 8);
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + cp * 2) * 4, 0);
 }
 
