@@ -62,9 +62,11 @@ typedef struct {
     float k_calibration;      /* 1941.05 (rpv2.cu:44) */
     int max_batch;    /* sectors processed per internal chunk of wrp_process_batch_device;
                          sizes the device workspace (0 = default) */
-    int flags;        /* bits 0-7: tuning, range-pass column tile (0 = best measured, 8 or 16);
+    int flags;        /* bits 0-7: tuning, column tile of the range pass / fused launch (0 = best
+                         measured, 8 or 16);
                          WRP_FLAG_FUSED: batches of >= 8 sectors run as ONE persistent launch whose
-                         XCD teams keep the intermediate in L2; other bits reserved, must be 0 */
+                         XCD teams keep the intermediate in L2 (measured slower than the default
+                         pair of kernels so far); other bits reserved, must be 0 */
 } wrp_config;
 
 #define WRP_FLAG_FUSED 0x100
@@ -151,8 +153,10 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
                           int iters, float *ms_total, float *ms_range, float *ms_doppler);
 
 /* Diagnostics: one fused launch with in-kernel phase stamps (100 MHz ticks) copied to
- * host_stamps[n_CUs][16 tasks][8]: 0 tile ready, 1 stages 1-2 done, 2 mid buffer free, 3 tile stored,
- * 4 team barrier passed, 5 Doppler rows done.  Synchronous; timing of this call is not representative. */
+ * host_stamps[workgroups][16 rounds][8] (workgroups = CUs, or 2 x CUs with 8-column tiles): 0 round start,
+ * 1 tile arrived, 2 stages 1-2 done, 3 stage 3 done and all tiles of the previous task stored, 4 row in
+ * registers, 5 row transformed (wave 0), 6 all waves done and all rows of the previous task loaded, 7 tile
+ * stores issued.  Synchronous; timing of this call is not representative. */
 int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                            unsigned long long *host_stamps, size_t host_count);
 
