@@ -139,7 +139,7 @@ def test_batch_larger_than_workspace_chunk(wrp, sectors):
 
 
 def test_fused_launch_matches_two_kernel_path(wrp, oracle, sectors):
-    """WRP_FLAG_FUSED: one persistent launch, XCD teams, intermediate in L2.  Same Doppler code; the
+    """WRP_FLAG_FUSED: one persistent launch, XCD teams, intermediate in L2 (both forms).  Same Doppler code; the
     range FFT is factored 8x16x8 instead of 16x8x8, so results agree to rounding: checked against
     the two-kernel path AND the fp64 oracle, for batch sizes that do and do not divide evenly among
     the teams, when the engine is reused (control block re-zeroed per launch), and run to run
@@ -153,8 +153,9 @@ def test_fused_launch_matches_two_kernel_path(wrp, oracle, sectors):
             assert np.all(np.isneginf(a[:, 0, 0]))
             assert np.max(np.abs(a[:, 1:] - b[:, 1:])) < 5e-5, count          # dB
             assert np.array_equal(a.view(np.uint32), ef.process_host(batch).view(np.uint32))
-            # two 512-thread workgroups per CU (8-column tiles, default) and one 1024-thread workgroup
-            # (16-column tiles) perform the same arithmetic per element
+            # tile + row workgroups (wrp_fused_roles.h, 8-column tiles, the default fused launch) and one
+            # 1024-thread workgroup doing both in rounds (wrp_fused.h, 16-column tiles) perform the same
+            # arithmetic per element
             assert np.array_equal(a.view(np.uint32), ef16.process_host(batch).view(np.uint32))
             for k in (0, count - 1):
                 check_final(a[k], oracle.sector(batch[k][0], batch[k][1], dtype=np.float64))

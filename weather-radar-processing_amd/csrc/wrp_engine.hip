@@ -16,6 +16,7 @@
 #include "wrp_kernels.h"
 #include "wrp_generic.h"
 #include "wrp_fused.h"
+#include "wrp_fused_roles.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 
@@ -52,7 +53,8 @@ struct wrp_engine {
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
     bool fused = false;
-    int fused_tcols = 8;
+    int fused_tcols = 8;            // 8: tile + row workgroups (wrp_fused_roles.h); 16: wrp_fused.h
+    int fused_in_aux = 0;           // cache policy of the tile loads of the 8-column launch (experiments: WRP_FUSED_IN_AUX)
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_mid_pool = nullptr;   // per XCD team: mid[2][m/2][n] + HH row sums
@@ -226,8 +228,17 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
                        dim3(wrp::FusedGeom<TC>::THREADS), wrp::FusedGeom<TC>::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, \
                        h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps, c.k_range_resolution, c.k_calibration, \
                        d_stamps)
-    if (h->fused_tcols == 8) { if (h->taps_pad == 7) WRP_FUSED(8, 7); else WRP_FUSED(8, 9); }
-    else { if (h->taps_pad == 7) WRP_FUSED(16, 7); else WRP_FUSED(16, 9); }
+#define WRP_ROLES(TAPS, AUX)                                                                                           \
+    hipLaunchKernelGGL((wrp::fused_roles_1024x512<TAPS, AUX>), dim3(h->n_cus * 2), dim3(wrp::FusedRoles::THREADS),   \
+                       wrp::FusedRoles::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors,   \
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
+    if (h->fused_tcols == 8) {          // tile workgroups + row workgroups, two per CU
+        if (h->fused_in_aux == 0) { if (h->taps_pad == 7) WRP_ROLES(7, 0); else WRP_ROLES(9, 0); }
+        else { if (h->taps_pad == 7) WRP_ROLES(7, 2); else WRP_ROLES(9, 2); }
+    } else {                            // one 1024-thread workgroup per CU doing both in rounds
+        if (h->taps_pad == 7) WRP_FUSED(16, 7); else WRP_FUSED(16, 9);
+    }
+#undef WRP_ROLES
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_timeout, &h->d_ctl->timeout, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -309,11 +320,16 @@ int create_impl(wrp_engine *h)
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
         h->n_cus = prop.multiProcessorCount;
     }
-    h->fused_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // two 512-thread workgroups per CU unless 16 is asked for
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<8, 7>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<8>::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<8, 9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<8>::LDS_BYTES));
+    h->fused_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // tile + row workgroups unless 16 is asked for
+    if (const char *e = getenv("WRP_FUSED_IN_AUX")) h->fused_in_aux = atoi(e) ? 2 : 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<7, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<9, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<7, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<9, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<16, 7>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<16>::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<16, 9>),

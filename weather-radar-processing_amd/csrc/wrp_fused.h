@@ -61,6 +61,7 @@ struct FusedCtl {               // zeroed by hipMemsetAsync before every launch;
     unsigned pad[6];
     unsigned stored[8][FUSED_RING][16];     // tiles of task q stored: slot q % RING, target ITEMS * (q / RING + 1)
     unsigned loaded[8][FUSED_RING][16];     // rows of task q in registers: target 512 * (q / RING + 1)
+    unsigned census_rows[8];                // fused_roles: row workgroups per XCC (census[] counts the tile workgroups)
 };
 constexpr int FUSED_STAMP_TASKS = 16;
 constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;              // one channel
@@ -142,7 +143,7 @@ __device__ __forceinline__ bool team_wait_ge(unsigned *p, unsigned target, unsig
 
 // this lane's 8 row loads (rows p0 + 128 r of one column pair) + its two Doppler-window values;
 // valid = false -> zero-record descriptor, all loads dropped (see range_load)
-template <int TCOLS>
+template <int TCOLS, int AUX = StreamAux<TCOLS>::value>
 __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-uniform */, int n, int col_base, const float *wd,
                                                 float4 (&v)[8], float2 &wdv, bool valid)
 {
@@ -155,7 +156,7 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     const int voff = (p0 * n + col_base + cp * 2) * 8;
 #pragma unroll
     // non-temporal: the input streams through the L2 once and must not push the team's buffer out of it
-    for (int r = 0; r < 8; r++) v[r] = buf_load_f4<StreamAux<TCOLS>::value>(rs, voff, 128 * r * n * 8);
+    for (int r = 0; r < 8; r++) v[r] = buf_load_f4<AUX>(rs, voff, 128 * r * n * 8);
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + cp * 2) * 4, 0);
 }
 
