@@ -6,9 +6,10 @@
 // Geometry, from the tile width TCOLS (8 or 16 columns):
 //   workgroup = 64 TCOLS threads (TCOLS waves); tiles per channel-task = 512 / TCOLS = members at
 //   work per team; rows per member and task = TCOLS (one per wave).
-//   TCOLS = 16: one 1024-thread workgroup per CU.  TCOLS = 8: TWO 512-thread workgroups per CU
-//   (80 KiB of LDS each), which drift apart and fill each other's LDS-bound, barrier and wait
-//   phases with arithmetic.
+//   TCOLS = 16: one 1024-thread workgroup per CU (the form the engine launches).  TCOLS = 8: two
+//   512-thread workgroups per CU (80 KiB of LDS each); measured slower (5.9 vs 3.9 us/sector: the
+//   range stages are latency-bound per wave) and not wired to a flag -- the engine's
+//   8-column fused launch is wrp_fused_roles.h, which shares the device functions below.
 // At start every workgroup reads the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never
 // assumed), registers with that XCD's team and the grid meets once.  Team e owns sectors e,
 // e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...; member r owns range tile r and the
@@ -235,7 +236,7 @@ __device__ __forceinline__ void fused_stage3_compute(const unsigned char *smem, 
 }
 
 // ... and the stores, which may happen much later
-template <int TCOLS>
+template <int TCOLS, int AUX = 0>
 __device__ __forceinline__ void fused_stage3_store(float2 *dst /* wave-uniform */, int n, int col_base, const float4 (&o)[4])
 {
     typedef FusedGeom<TCOLS> G;
@@ -246,7 +247,7 @@ __device__ __forceinline__ void fused_stage3_store(float2 *dst /* wave-uniform *
     const int voff = ((k1 + 8 * k2) * n + col_base + cp * 2) * 8;
 #pragma unroll
     for (int k3 = 0; k3 < 4; k3++)   // gates < m/2 only; row offset in the VGPR (see buf_store_f4)
-        buf_store_f4(rd, voff + 128 * k3 * n * 8, 0, o[k3]);
+        buf_store_f4<AUX>(rd, voff + 128 * k3 * n * 8, 0, o[k3]);
 }
 
 template <int TCOLS, int TAPS>
