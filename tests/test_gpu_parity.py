@@ -193,6 +193,34 @@ def test_vh_plane_is_carried_but_ignored(wrp, sectors):
         assert np.array_equal(e3.process_host(iq3), e2.process_host(sectors[1][None]))
 
 
+def test_special_values_compare_by_class(wrp, oracle, sectors):
+    """NaN / inf compared by class.  An all-zero sector (S = 0: Zdb = -inf, Zdr = NaN), a
+    silent VV channel (Zdr = +inf), one NaN sample and one inf sample (they poison their channel's column
+    in the range FFT and from there every gate) -- default path and both fused launches against the
+    fp64 oracle; the ordinary sectors of the same batch must be unaffected."""
+    base = sectors[1]
+    zero = np.zeros_like(base)
+    vv_silent = base.copy()
+    vv_silent[1] = 0
+    one_nan = base.copy()
+    one_nan[0, 700, 33] = np.nan
+    one_inf = base.copy()
+    one_inf[1, 5, 500] = np.inf + 0j
+    batch = np.stack([base, zero, vv_silent, one_nan, one_inf, base, sectors[2], zero, base])
+    want = np.stack([oracle.sector(s[0], s[1], dtype=np.float64) for s in batch])
+    for flags in (0, 0x100, 0x110):
+        with wrp.Engine(device=0, n_slots=1, flags=flags) as e:
+            got = e.process_host(batch)
+        for cls in (np.isnan, np.isposinf, np.isneginf):
+            assert np.array_equal(cls(got), cls(want)), (flags, cls.__name__)
+        fin = np.isfinite(want)
+        assert np.max(np.abs(got[fin] - want[fin])) < 1e-3, flags          # dB
+        assert np.array_equal(got[0], got[5]) and np.array_equal(got[0], got[8])
+    assert np.all(np.isneginf(want[1, :, 0])) and np.all(np.isnan(want[1, :, 1]))
+    assert np.all(np.isposinf(want[2, 1:, 1]))
+    assert np.all(np.isnan(want[3, 1:, 0])) and np.all(np.isnan(want[4, :, 1]))
+
+
 def test_scaling_property(engine, sectors):
     """Size-independent property at full size: IQ -> 2 IQ shifts Zdb by 20 log10 2, keeps Zdr."""
     base = engine.process_host(sectors[2][None])[0]
