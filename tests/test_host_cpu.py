@@ -65,3 +65,19 @@ def test_result_framing_matches_oracle(host, oracle):
                                        out.ctypes.data_as(C.POINTER(C.c_ubyte)))
             want = oracle.frame_result(z, 0x0142, 0x0008, which, with_elevation=bool(with_elev))
             assert n == want.size and np.array_equal(out[:n], want)
+
+
+def test_tcp_endpoints_echo_acknowledged_messages(host):
+    """tcp::tcpclient / tcp::tcpserver keep the reference's names and signatures (tcp.h:8-30): the server
+    accepts one peer, recv() reads a message and echoes it, sendit() waits for that echo.  Loop-back over
+    127.0.0.1 with messages larger than a socket buffer (partial reads and writes must be completed)."""
+    import socket
+    with socket.socket() as s:                 # a port nobody is using right now
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    host.wrph_tcp_loopback.restype = C.c_int
+    assert host.wrph_tcp_loopback(port, 3, 12 * 512) == 0          # one radar row per message (read_single.cc:145-148)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    assert host.wrph_tcp_loopback(port, 2, 3 << 20) == 0           # 3 MiB: needs many reads / writes

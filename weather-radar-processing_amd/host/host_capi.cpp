@@ -1,10 +1,16 @@
 // host_capi.cpp -- C-linkage view of the host types for tests and non-C++ callers.
 #include <string.h>
 
+#include <chrono>
+#include <memory>
+#include <thread>
+#include <vector>
+
 #include "dimension.h"
 #include "floats.h"
 #include "framing.h"
 #include "sector.h"
+#include "tcp.h"
 
 extern "C" {
 
@@ -28,6 +34,47 @@ size_t wrph_frame_result(const float *zdb_zdr, int gates, int sector, int elevat
                          unsigned char *out)
 {
     return frame_result(zdb_zdr, gates, sector, elevation, which, with_elevation != 0, out);
+}
+
+// tcp.h loop-back exercise: a tcpserver thread on `port` receives `messages` messages of `length` bytes
+// from a tcpclient in the calling thread.  Returns 0 when every message arrived intact and every
+// sendit() saw its acknowledgement; a negative code says which step failed.
+int wrph_tcp_loopback(int port, int messages, int length)
+{
+    std::vector<std::vector<char>> got(messages, std::vector<char>(length));
+    int server_rc = 0;
+    std::thread server([&] {
+        try {
+            tcp::tcpserver s(port);
+            for (int k = 0; k < messages; k++)
+                if (s.recv(got[k].data(), (size_t)length) != length) { server_rc = -2; return; }
+        } catch (const char *) { server_rc = -1; }
+    });
+    int rc = 0;
+    try {
+        // the server may not be listening yet: connect refused -> retry for up to two seconds
+        std::unique_ptr<tcp::tcpclient> c;
+        for (int attempt = 0; attempt < 200 && !c; attempt++) {
+            try { c.reset(new tcp::tcpclient(port)); }
+            catch (const char *) { std::this_thread::sleep_for(std::chrono::milliseconds(10)); }
+        }
+        if (!c) rc = -3;
+        std::vector<char> msg(length);
+        for (int k = 0; k < messages && rc == 0; k++) {
+            for (int i = 0; i < length; i++) msg[i] = (char)(31 * i + 7 * k + 1);
+            if (c->sendit(msg.data(), (size_t)length) != 0) rc = -4;
+        }
+    } catch (const char *) { rc = -5; }
+    if (rc == -3) {   // never connected: the server thread either failed to bind (and has ended) or waits in accept
+        server.detach();
+        return server_rc != 0 ? server_rc : rc;
+    }
+    server.join();
+    if (rc == 0 && server_rc != 0) rc = server_rc;
+    for (int k = 0; k < messages && rc == 0; k++)
+        for (int i = 0; i < length; i++)
+            if (got[k][i] != (char)(31 * i + 7 * k + 1)) { rc = -6; break; }
+    return rc;
 }
 
 } // extern "C"
