@@ -54,7 +54,7 @@ struct wrp_engine {
     // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
     bool fused = false;
     int fused_tcols = 8;            // 8: tile + row workgroups (wrp_fused_roles.h); 16: wrp_fused.h
-    int fused_in_aux = 0;          // cache policy of the tile loads of the 8-column launch (experiments: WRP_FUSED_IN_AUX)
+    int fused_in_aux = 2;          // tile loads of the 8-column launch: nt (5.13 us/sector) or plain (5.34); WRP_FUSED_IN_AUX=0|1
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_mid_pool = nullptr;   // per XCD team: mid[2][m/2][n] + HH row sums
