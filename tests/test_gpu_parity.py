@@ -163,6 +163,26 @@ def test_fused_launch_matches_two_kernel_path(wrp, oracle, sectors):
         assert np.array_equal(ef.process_host(batch[:3]), b[:3])
 
 
+def test_fused_launch_at_eight_waves_per_simd(wrp, oracle, sectors, monkeypatch):
+    """wrp_fused64.h (experimental, WRP_FUSED64=1): tile + row workgroups of 1024 threads, 64 VGPRs, the
+    range FFT factored 8x8x16 with a pruned last stage.  Another factorisation -> agrees to rounding with the
+    default path and the oracle; bit-reproducible; kinds are chosen per physical CU at run time."""
+    monkeypatch.setenv("WRP_FUSED64", "1")
+    with wrp.Engine(device=0, n_slots=1, flags=0x100) as e64:
+        monkeypatch.delenv("WRP_FUSED64")
+        with wrp.Engine(device=0, n_slots=1) as e2:
+            for count in (8, 21):
+                batch = np.stack([sectors[(k + 2) % 3] * np.float32(1 + 0.5 * (k % 3)) for k in range(count)])
+                a = e64.process_host(batch)
+                b = e2.process_host(batch)
+                assert np.all(np.isneginf(a[:, 0, 0]))
+                assert np.max(np.abs(a[:, 1:] - b[:, 1:])) < 5e-5, count          # dB
+                assert np.array_equal(a.view(np.uint32), e64.process_host(batch).view(np.uint32))
+                for k in (0, count - 1):
+                    check_final(a[k], oracle.sector(batch[k][0], batch[k][1], dtype=np.float64))
+            assert not np.array_equal(a, b)      # really a different launch, not the default path
+
+
 def test_wire_format_ingest_is_bit_identical_to_cpu_decode(wrp, oracle):
     """N1: raw 12 B/sample big-endian int16 upload + GPU decode == Sector::fromByteArray + the
     int16->float2 scatter of rpv2.cu:369-383 (oracle restatement, itself pinned by the reference's

@@ -41,9 +41,19 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "roles_stamps.npy"), st)
     t = st.astype(np.float64) / 100.0
-    tiles, rows = t[: nwg // 2], t[nwg // 2:]
+    kind = st[:, 0, 5]                       # wrp_fused64.h records the kind it took at run time (1 tile, 2 rows)
+    if kind.max() > 0:
+        tiles, rows = t[kind == 1], t[kind == 2]
+        print(f"{(kind == 1).sum()} tile workgroups, {(kind == 2).sum()} row workgroups (kind chosen per physical CU)")
+    else:
+        tiles, rows = t[: nwg // 2], t[nwg // 2:]
     print("tile workgroups, items 4..15 (us: median, p10 .. p90)")
     show("stages 1-3 of one 8-column tile", tiles[:, 4:, 1] - tiles[:, 4:, 0])
+    if st[:, 4:, 7].max() > 0:             # wrp_fused64.h: finer stamps
+        show("   wait tile arrival", tiles[:, 4:, 4] - tiles[:, 4:, 0])
+        show("   stage 1 + barrier", tiles[:, 4:, 6] - tiles[:, 4:, 4])
+        show("   tile request + stage 2 + barrier", tiles[:, 4:, 7] - tiles[:, 4:, 6])
+        show("   stage 3 arithmetic", tiles[:, 4:, 1] - tiles[:, 4:, 7])
     show("wait buffer free (first tile of a task)", (tiles[:, 4:, 2] - tiles[:, 4:, 1])[:, 0::2])
     show("barrier only (second tile)", (tiles[:, 4:, 2] - tiles[:, 4:, 1])[:, 1::2])
     show("stores (first tile)", (tiles[:, 4:, 3] - tiles[:, 4:, 2])[:, 0::2])

@@ -17,6 +17,7 @@
 #include "wrp_generic.h"
 #include "wrp_fused.h"
 #include "wrp_fused_roles.h"
+#include "wrp_fused64.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 
@@ -54,7 +55,8 @@ struct wrp_engine {
     // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
     bool fused = false;
     int fused_tcols = 8;            // 8: tile + row workgroups (wrp_fused_roles.h); 16: wrp_fused.h
-    int fused_in_aux = 2;          // tile loads of the 8-column launch: nt (5.13 us/sector) or plain (5.34); WRP_FUSED_IN_AUX=0|1
+    bool fused64 = false;           // 8-column launch at 8 waves per SIMD (wrp_fused64.h); WRP_FUSED64=1
+    int fused_in_aux = 2;         // tile loads of the 8-column launch: nt (5.13 us/sector) or plain (5.34); WRP_FUSED_IN_AUX=0|1
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_mid_pool = nullptr;   // per XCD team: mid[2][m/2][n] + HH row sums
@@ -232,12 +234,20 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     hipLaunchKernelGGL((wrp::fused_roles_1024x512<TAPS, AUX>), dim3(h->n_cus * 2), dim3(wrp::FusedRoles::THREADS),   \
                        wrp::FusedRoles::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors,   \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
+#define WRP_F64(TAPS)                                                                                                  \
+    hipLaunchKernelGGL((wrp::fused64_1024x512<TAPS>), dim3(h->n_cus * 2), dim3(wrp::F64::THREADS), wrp::F64::LDS_BYTES, \
+                       st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,        \
+                       c.k_range_resolution, c.k_calibration, d_stamps)
+    if (h->fused_tcols == 8 && h->fused64) {   // tile + row workgroups of 1024 threads, 8 waves per SIMD
+        if (h->taps_pad == 7) WRP_F64(7); else WRP_F64(9);
+    } else
     if (h->fused_tcols == 8) {          // tile workgroups + row workgroups, two per CU
         if (h->fused_in_aux == 0) { if (h->taps_pad == 7) WRP_ROLES(7, 0); else WRP_ROLES(9, 0); }
         else { if (h->taps_pad == 7) WRP_ROLES(7, 2); else WRP_ROLES(9, 2); }
     } else {                            // one 1024-thread workgroup per CU doing both in rounds
         if (h->taps_pad == 7) WRP_FUSED(16, 7); else WRP_FUSED(16, 9);
     }
+#undef WRP_F64
 #undef WRP_ROLES
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
@@ -322,6 +332,11 @@ int create_impl(wrp_engine *h)
     }
     h->fused_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // tile + row workgroups unless 16 is asked for
     if (const char *e = getenv("WRP_FUSED_IN_AUX")) h->fused_in_aux = atoi(e) ? 2 : 0;
+    if (const char *e = getenv("WRP_FUSED64")) h->fused64 = atoi(e) != 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused64_1024x512<7>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::F64::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused64_1024x512<9>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::F64::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<7, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<9, 0>),

@@ -63,6 +63,7 @@ struct FusedCtl {               // zeroed by hipMemsetAsync before every launch;
     unsigned stored[8][FUSED_RING][16];     // tiles of task q stored: slot q % RING, target ITEMS * (q / RING + 1)
     unsigned loaded[8][FUSED_RING][16];     // rows of task q in registers: target 512 * (q / RING + 1)
     unsigned census_rows[8];                // fused_roles: row workgroups per XCC (census[] counts the tile workgroups)
+    unsigned cu_arrivals[8][256];           // fused64: workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
 };
 constexpr int FUSED_STAMP_TASKS = 16;
 constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;              // one channel
@@ -106,10 +107,13 @@ __device__ __forceinline__ void l2_count(unsigned *p)
 }
 __device__ __forceinline__ unsigned l2_peek(unsigned *p)
 {
-    // an atomic add of 0 with return: performed at the L2 like every atomic, so it cannot hit a
-    // stale line of the CU's L1 (an sc0 load does -- measured: the poll never saw the count).
-    // The zero is hidden from the compiler, which otherwise folds the idempotent atomic into
-    // exactly that sc0 load.
+    // An atomic add of 0 with return: performed at the L2 like every atomic, so it cannot hit a stale
+    // line of the CU's L1.  The zero is hidden from the compiler, which otherwise folds the idempotent
+    // atomic into an sc0 load.  Every alternative was measured worse on MI355X (the rounds launch of
+    // this file, us/sector): sc0 load -- never sees the count (stale L1 line); device-scope (sc1) load
+    // 5.7; non-temporal load 7.2 (sees it late); this 3.9.  Its weakness: dozens of workgroups polling
+    // ONE line serialise in the L2's atomic unit (2.7 us median, 4.8 us worst, to notice a count in the
+    // tile/row launches, where 32 workgroups poll for most of a task) -- poll rarely, or per-waiter lines.
     unsigned zero = 0;
     asm volatile("" : "+v"(zero));
     return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
