@@ -62,21 +62,26 @@ typedef struct {
     float k_calibration;      /* 1941.05 (rpv2.cu:44) */
     int max_batch;    /* sectors processed per internal chunk of wrp_process_batch_device;
                          sizes the device workspace (0 = default) */
-    int flags;        /* bits 0-7: tuning, column tile of the range pass / fused launch (0 = best
-                         measured, 8 or 16);
-                         WRP_FLAG_FUSED: batches of >= 8 sectors run as ONE persistent launch whose
-                         XCD teams keep the intermediate in L2 (measured slower than the default
-                         pair of kernels so far); other bits reserved, must be 0 */
+    int flags;        /* 0 = the best measured configuration.  Bits 0-7: tuning, column tile of the
+                         two-kernel range pass (8 or 16); WRP_FLAG_* below; other bits must be 0 */
 } wrp_config;
 
+/* The m = 1024, n = 512 shape runs batches of >= WRP_FUSED_MIN_SECTORS sectors as ONE persistent
+ * launch whose XCD teams hand the intermediate from the range FFT to the Doppler rows through
+ * their L2 (csrc/wrp_fused.h); smaller batches, the slot cascade (wrp_submit) and all other
+ * shapes run a range-pass kernel and a Doppler-pass kernel.  Both forms perform the same
+ * arithmetic and give bit-identical results.
+ * WRP_FLAG_FUSED      : accepted for compatibility (the fused launch is the default);
+ * WRP_FLAG_TWO_KERNELS: never use the fused launch (A/B measurements, parity tests). */
 #define WRP_FLAG_FUSED 0x100
-/* batches larger than max_batch: run the range pass of chunk k+1 beside the Doppler pass of
- * chunk k on two internal streams (joined to the caller's stream by events) */
-#define WRP_FLAG_OVERLAP 0x200
-/* By default the range pass is a fixed grid that walks the tiles and requests the next tile
- * while the current one is being transformed.  This flag selects the one-tile-per-workgroup
- * form instead (same arithmetic, bit-identical results; kept for A/B measurements). */
+#define WRP_FLAG_TWO_KERNELS 0x800
+#define WRP_FUSED_MIN_SECTORS 8
+/* By default the two-kernel range pass is a fixed grid that walks the tiles and requests the
+ * next tile while the current one is being transformed.  This flag selects the
+ * one-tile-per-workgroup form instead (same arithmetic, bit-identical results; A/B only). */
 #define WRP_FLAG_ONE_TILE_PER_BLOCK 0x400
+/* tuning: the fused launch polls its team counters with device-scope loads instead of L2 atomics */
+#define WRP_FLAG_FUSED_POLL_LOAD 0x1000
 
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
 typedef enum {
@@ -136,13 +141,23 @@ int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr);
  * stream: hipStream_t as void*, NULL = the engine's compute stream.  Asynchronous. */
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream);
 int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream);
+/* ONE batch is in flight per handle (the workspace is shared): a batch submitted on another
+ * stream first waits, on the device, for the previous one.
+ * The fused launch needs all its workgroups resident at once and says so when they are not
+ * (e.g. another kernel occupies CUs): wrp_check waits for the handle's last batch and returns
+ * WRP_ERR_HIP (text in wrp_last_hip_error) if a fused launch since the previous check gave up;
+ * d_out of that batch is then undefined, the handle has switched to the two-kernel path and the
+ * batch must be submitted again.  wrp_process_host and wrp_time_batch_device check by themselves. */
+int wrp_check(wrp_handle h);
 
 /* Synchronous convenience: host buffers in the same layouts (pageable or pinned). */
 int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *out_host);
 
 /* Debug/parity: re-run the chain on the slot's device IQ block (as last uploaded by
  * wrp_submit) with stage dumping enabled and copy stage `stage` of `channel`
- * (0 = HH, 1 = VV, 2 = VH) to host_out (sizes per wrp_stage). Synchronous. */
+ * (0 = HH, 1 = VV; VH is carried but never processed: WRP_ERR_INVALID) to host_out (sizes per
+ * wrp_stage).  Dumps come from the two-kernel form, whose results the fused launch reproduces
+ * bit for bit (tested).  Synchronous. */
 int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_out);
 
 /* Measurement: run `iters` back-to-back wrp_process_batch_device calls on the engine's
@@ -152,11 +167,12 @@ int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_ou
 int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                           int iters, float *ms_total, float *ms_range, float *ms_doppler);
 
-/* Diagnostics: one fused launch with in-kernel phase stamps (100 MHz ticks) copied to
- * host_stamps[workgroups][16 rounds][8] (workgroups = CUs, or 2 x CUs with 8-column tiles): 0 round start,
- * 1 tile arrived, 2 stages 1-2 done, 3 stage 3 done and all tiles of the previous task stored, 4 row in
- * registers, 5 row transformed (wave 0), 6 all waves done and all rows of the previous task loaded, 7 tile
- * stores issued.  Synchronous; timing of this call is not representative. */
+/* Diagnostics: one fused launch (a separate instantiation) with in-kernel phase stamps (100 MHz
+ * ticks) copied to host_stamps[2 x CUs workgroups][16 tasks][8].  Slot 7 of task 0 identifies the
+ * workgroup: kind << 32 | xcc << 16 | rank.  Tile workgroups (kind 0): 0 task start, 1 stage 1 done,
+ * 2 group 0 transformed and the previous task's rows loaded, 3 all stores issued, 4 stores drained
+ * and counted.  Row workgroups (kind 1): 0 task start, 1 all tiles stored, 2 rows in registers and
+ * counted, 3 rows transformed (wave 0).  Synchronous; timing of this call is not representative. */
 int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                            unsigned long long *host_stamps, size_t host_count);
 

@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # torch bundles its own HIP runtime: when libwrp.so has initialised the GPU first, torch finds
+    # "no HIP GPUs".  GPU tests that use torch for device memory need torch to come first.
+    if any(it.get_closest_marker("gpu") for it in items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

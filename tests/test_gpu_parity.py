@@ -138,49 +138,48 @@ def test_batch_larger_than_workspace_chunk(wrp, sectors):
         assert e.process_host(batch[:0]).shape == (0, 512, 2)       # empty batch is a no-op
 
 
-def test_fused_launch_matches_two_kernel_path(wrp, oracle, sectors):
-    """WRP_FLAG_FUSED: one persistent launch, XCD teams, intermediate in L2 (both forms).  Same Doppler code; the
-    range FFT is factored 8x16x8 instead of 16x8x8, so results agree to rounding: checked against
-    the two-kernel path AND the fp64 oracle, for batch sizes that do and do not divide evenly among
-    the teams, when the engine is reused (control block re-zeroed per launch), and run to run
-    (the fused launch itself must be deterministic bit for bit)."""
-    with wrp.Engine(device=0, n_slots=1, flags=0x100) as ef, wrp.Engine(device=0, n_slots=1, flags=0x110) as ef16, \
-            wrp.Engine(device=0, n_slots=1) as e2:
+def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, oracle, sectors):
+    """The default for batches of >= 8 sectors: ONE persistent launch, tile + row workgroups on every CU,
+    XCD teams handing the intermediate over through their L2 (csrc/wrp_fused.h).  It performs the arithmetic
+    of the two-kernel path element for element, so the results must agree BIT FOR BIT -- for batch sizes
+    that do and do not divide evenly among the teams, when the engine is reused (control block re-zeroed
+    per launch), with either way of polling the team counters, and against the fp64 oracle."""
+    with wrp.Engine(device=0, n_slots=1) as ef, wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_FUSED_POLL_LOAD) as efl, \
+            wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
         for count in (8, 19, 50):
             batch = np.stack([sectors[(3 * k + 1) % 3] * np.float32(1 + 0.25 * (k % 5)) for k in range(count)])
             a = ef.process_host(batch)
             b = e2.process_host(batch)
             assert np.all(np.isneginf(a[:, 0, 0]))
-            assert np.max(np.abs(a[:, 1:] - b[:, 1:])) < 5e-5, count          # dB
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), count
             assert np.array_equal(a.view(np.uint32), ef.process_host(batch).view(np.uint32))
-            # tile + row workgroups (wrp_fused_roles.h, 8-column tiles, the default fused launch) and one
-            # 1024-thread workgroup doing both in rounds (wrp_fused.h, 16-column tiles) perform the same
-            # arithmetic per element
-            assert np.array_equal(a.view(np.uint32), ef16.process_host(batch).view(np.uint32))
+            assert np.array_equal(a.view(np.uint32), efl.process_host(batch).view(np.uint32))
             for k in (0, count - 1):
                 check_final(a[k], oracle.sector(batch[k][0], batch[k][1], dtype=np.float64))
-        # fewer than 8 sectors falls back to the two-kernel path by design
+        assert ef.lib.wrp_last_hip_error(ef.handle) == b""          # no fallback happened on the way
+        # fewer than 8 sectors run the two kernels by design
         assert np.array_equal(ef.process_host(batch[:3]), b[:3])
 
 
-def test_fused_launch_at_eight_waves_per_simd(wrp, oracle, sectors, monkeypatch):
-    """wrp_fused64.h (experimental, WRP_FUSED64=1): tile + row workgroups of 1024 threads, 64 VGPRs, the
-    range FFT factored 8x8x16 with a pruned last stage.  Another factorisation -> agrees to rounding with the
-    default path and the oracle; bit-reproducible; kinds are chosen per physical CU at run time."""
-    monkeypatch.setenv("WRP_FUSED64", "1")
-    with wrp.Engine(device=0, n_slots=1, flags=0x100) as e64:
-        monkeypatch.delenv("WRP_FUSED64")
-        with wrp.Engine(device=0, n_slots=1) as e2:
-            for count in (8, 21):
-                batch = np.stack([sectors[(k + 2) % 3] * np.float32(1 + 0.5 * (k % 3)) for k in range(count)])
-                a = e64.process_host(batch)
-                b = e2.process_host(batch)
-                assert np.all(np.isneginf(a[:, 0, 0]))
-                assert np.max(np.abs(a[:, 1:] - b[:, 1:])) < 5e-5, count          # dB
-                assert np.array_equal(a.view(np.uint32), e64.process_host(batch).view(np.uint32))
-                for k in (0, count - 1):
-                    check_final(a[k], oracle.sector(batch[k][0], batch[k][1], dtype=np.float64))
-            assert not np.array_equal(a, b)      # really a different launch, not the default path
+def test_fused_launch_through_the_device_entry_and_check(wrp, sectors):
+    """wrp_process_batch_device is asynchronous: wrp_check reports a fused launch that gave up.  Here it
+    must report success, on the engine's stream and on a caller's stream, back to back (one batch in
+    flight per handle: the second waits for the first on the device)."""
+    import torch
+    count = 16
+    batch = np.stack([sectors[k % 3] * np.float32(1 + k) for k in range(count)])
+    d_in = torch.from_numpy(batch.view(np.float32)).cuda()
+    d_a = torch.zeros(count, M // 2, 2, device="cuda")
+    d_b = torch.zeros_like(d_a)
+    side = torch.cuda.Stream()
+    with wrp.Engine(device=0, n_slots=1) as e:
+        want = e.process_host(batch)
+        e.process_batch_device(d_in.data_ptr(), count, d_a.data_ptr())
+        e.process_batch_device(d_in.data_ptr(), count, d_b.data_ptr(), stream=side.cuda_stream)
+        e.check()
+        torch.cuda.synchronize()
+    assert np.array_equal(d_a.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(d_b.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
 def test_wire_format_ingest_is_bit_identical_to_cpu_decode(wrp, oracle):
@@ -216,7 +215,7 @@ def test_vh_plane_is_carried_but_ignored(wrp, sectors):
 def test_special_values_compare_by_class(wrp, oracle, sectors):
     """NaN / inf compared by class.  An all-zero sector (S = 0: Zdb = -inf, Zdr = NaN), a
     silent VV channel (Zdr = +inf), one NaN sample and one inf sample (they poison their channel's column
-    in the range FFT and from there every gate) -- default path and both fused launches against the
+    in the range FFT and from there every gate) -- fused launch and two-kernel path against the
     fp64 oracle; the ordinary sectors of the same batch must be unaffected."""
     base = sectors[1]
     zero = np.zeros_like(base)
@@ -228,7 +227,7 @@ def test_special_values_compare_by_class(wrp, oracle, sectors):
     one_inf[1, 5, 500] = np.inf + 0j
     batch = np.stack([base, zero, vv_silent, one_nan, one_inf, base, sectors[2], zero, base])
     want = np.stack([oracle.sector(s[0], s[1], dtype=np.float64) for s in batch])
-    for flags in (0, 0x100, 0x110):
+    for flags in (0, wrp.FLAG_TWO_KERNELS):
         with wrp.Engine(device=0, n_slots=1, flags=flags) as e:
             got = e.process_host(batch)
         for cls in (np.isnan, np.isposinf, np.isneginf):

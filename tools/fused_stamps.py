@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Phase anatomy of the fused launch (wrp_debug_fused_stamps).  Every workgroup stamps its first 16
-rounds (s_memrealtime, 100 MHz): 0 round start, 1 tile arrived, 2 stages 1-2 done, 3 stage 3 done and
-all tiles of the previous task stored, 4 row in registers (wave 0), 5 row transformed (wave 0),
-6 all waves done and all rows of the previous task loaded, 7 tile stores issued."""
+"""Phase anatomy of the fused launch (wrp_debug_fused_stamps, a separate diagnostic instantiation).
+Every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 7 of task 0 holds
+kind << 32 | xcc << 16 | rank.
+  tile workgroups: 0 task start, 1 stage 1 done (tile had arrived), 2 group 0 transformed + previous rows
+                   loaded, 3 all stores issued, 4 stores drained and counted
+  row workgroups : 0 task start, 1 all tiles stored, 2 rows in registers and counted, 3 rows transformed
+Read the SHARES, not the length: stamps forbid overlaps the real launch has."""
 import ctypes as C
 import os
 import sys
@@ -23,31 +26,36 @@ def main():
     d_pool = torch.from_numpy(pool.view(np.float32).reshape(2, -1)).to(dev)
     d_iq = d_pool[torch.arange(S, device=dev) % 2].contiguous()
     d_out = torch.empty((S, 512, 2), dtype=torch.float32, device=dev)
-    tcols = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    eng = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, flags=0x100 | tcols)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count * (2 if tcols == 8 else 1)
-    st = np.zeros((ncu, 16, 8), np.uint64)
+    eng = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1)
+    nwg = torch.cuda.get_device_properties(0).multi_processor_count * 2
+    st = np.zeros((nwg, 16, 8), np.uint64)
     lib = eng.lib
-    lib.wrp_debug_fused_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     for _ in range(2):
         rc = lib.wrp_debug_fused_stamps(eng.handle, C.c_void_p(d_iq.data_ptr()), S, C.c_void_p(d_out.data_ptr()),
                                         st.ctypes.data_as(C.c_void_p), st.size)
-        assert rc == 0, rc
+        assert rc == 0, (rc, lib.wrp_last_hip_error(eng.handle))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "stamps.npy"), st)
+    ident = st[:, 0, 7]
+    kind = (ident >> np.uint64(32)).astype(int)
+    xcc = ((ident >> np.uint64(16)) & np.uint64(0xffff)).astype(int)
+    print("workgroups per (kind, xcc):", {(k, x): int(((kind == k) & (xcc == x)).sum()) for k in (0, 1) for x in range(8)})
     t = st.astype(np.float64) / 100.0     # us
-    rounds = min(16, 2 * (S // 8))
-    r = slice(2, rounds)                   # steady state: both halves of the round present
-    names = ["wait tile arrival", "stages 1-2 (+ count, tile request)", "stage 3 + wait tiles stored", "row load (wave 0)",
-             "row transform (wave 0)", "other waves + wait rows loaded", "tile stores issued"]
-    d = np.diff(t[:, r, :], axis=2)
-    print(f"{ncu} workgroups, rounds 2..{rounds - 1}; median (p10 .. p90) us")
-    for k, nm in enumerate(names):
-        x = d[:, :, k].ravel()
-        print(f"    {nm:36s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
-    per_round = np.diff(t[:, r, 0], axis=1).ravel()
-    print(f"round: median {np.median(per_round):.2f} us (p10 {np.percentile(per_round, 10):.2f}, p90 {np.percentile(per_round, 90):.2f})"
-          f"  -> {np.median(per_round) * 2 / 8:.2f} us/sector with 8 teams")
+    tasks = min(16, 2 * (S // 8))
+    r = slice(3, tasks)
+    names = {0: ["stage 1 (incl. wait for the tile)", "group 0 stages 2-3 + wait rows loaded", "store, group 1, prefetch, stores",
+                 "drain + barrier + count"],
+             1: ["wait tiles stored", "row loads + barrier + count", "two row transforms (wave 0)"]}
+    for k, label in ((0, "tile"), (1, "row")):
+        sel = kind == k
+        d = np.diff(t[sel][:, r, :len(names[k]) + 1], axis=2)
+        print(f"{label} workgroups ({int(sel.sum())}), tasks 3..{tasks - 1}; median (p10 .. p90) us")
+        for i, nm in enumerate(names[k]):
+            x = d[:, :, i].ravel()
+            print(f"    {nm:42s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
+        per = np.diff(t[sel][:, r, 0], axis=1).ravel()
+        print(f"    task period: median {np.median(per):.2f} us (p10 {np.percentile(per, 10):.2f}, p90 {np.percentile(per, 90):.2f})"
+              f"  -> {np.median(per) * 2 / 8:.2f} us/sector with 8 teams")
     eng.close()
 
 

@@ -26,6 +26,9 @@ class WrpConfig(C.Structure):
     ]
 
 
+FLAG_FUSED, FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_FUSED_POLL_LOAD = 0x100, 0x400, 0x800, 0x1000
+FUSED_MIN_SECTORS = 8
+
 STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7}
 
 
@@ -84,6 +87,7 @@ def load_library():
     lib.wrp_process_device.argtypes = [vp, vp, vp, vp]
     lib.wrp_process_batch_device.argtypes = [vp, vp, i, vp, vp]
     lib.wrp_process_host.argtypes = [vp, vp, i, vp]
+    lib.wrp_check.argtypes = [vp]
     lib.wrp_dump_stage.argtypes = [vp, i, i, i, vp]
     lib.wrp_time_batch_device.argtypes = [vp, vp, i, vp, i, fp, fp, fp]
     lib.wrp_get_config.argtypes = [vp, C.POINTER(WrpConfig)]
@@ -203,6 +207,10 @@ class Engine:
         self._check(self.lib.wrp_process_batch_device(self._h, C.c_void_p(d_iq_ptr), n_sectors,
                                                       C.c_void_p(d_out_ptr), C.c_void_p(stream or 0)),
                     "wrp_process_batch_device")
+
+    def check(self):
+        """Wait for the last batch; raises if a fused launch since the previous check gave up."""
+        self._check(self.lib.wrp_check(self._h), "wrp_check")
 
     def time_batch_device(self, d_iq_ptr, n_sectors, d_out_ptr, iters, per_kernel=False):
         """HIP-event timing on the engine's own stream -> (ms_total, ms_range, ms_doppler)."""

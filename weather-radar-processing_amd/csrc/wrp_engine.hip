@@ -16,8 +16,6 @@
 #include "wrp_kernels.h"
 #include "wrp_generic.h"
 #include "wrp_fused.h"
-#include "wrp_fused_roles.h"
-#include "wrp_fused64.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 
@@ -52,22 +50,18 @@ struct wrp_engine {
     bool tuned = true;        // m = 1024, n = 512: tuned kernels; otherwise wrp_generic.h
     bool persist = false;     // range pass as a fixed grid walking the tiles with prefetch
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
-    // fused persistent launch (cfg.flags & WRP_FLAG_FUSED)
+    // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors
     bool fused = false;
-    int fused_tcols = 8;            // 8: tile + row workgroups (wrp_fused_roles.h); 16: wrp_fused.h
-    bool fused64 = false;           // 8-column launch at 8 waves per SIMD (wrp_fused64.h); WRP_FUSED64=1
-    int fused_in_aux = 2;         // tile loads of the 8-column launch: nt (5.13 us/sector) or plain (5.34); WRP_FUSED_IN_AUX=0|1
+    bool fused_poll_load = false;   // counters polled with sc1 loads instead of L2 atomics (tuning)
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
-    float2 *d_mid_pool = nullptr;   // per XCD team: mid[2][m/2][n] + HH row sums
-    unsigned *h_timeout = nullptr;  // pinned copy of FusedCtl::timeout after the last fused launch
-    // chunk pipeline (cfg.flags & WRP_FLAG_OVERLAP): range pass of chunk k+1 beside Doppler pass of chunk k
-    bool overlap = false;
-    hipStream_t st_range = nullptr, st_dopp = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_range[2] = {nullptr, nullptr}, ev_dopp[2] = {nullptr, nullptr};
-    float2 *d_mid2 = nullptr;
-    // batch workspace
+    float2 *d_mid_pool = nullptr;   // per XCD team: ONE mid[m/2][n]
+    unsigned *h_status = nullptr;   // pinned: FusedCtl::status of every fused launch so far, OR-ed by the device copy order
+    int fused_launches = 0;         // launches whose status has not been looked at yet
+    // batch workspace; one batch in flight per handle: the next batch's stream waits for ev_batch
     hipStream_t stream = nullptr;
+    hipEvent_t ev_batch = nullptr;
+    bool batch_pending = false;
     float2 *d_mid = nullptr;  // [max_batch][2][m/2][n]
     int max_batch = 0;
     // slots + host result table [elev][sector][gate][2]
@@ -218,41 +212,47 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
     }
 }
 
-// one persistent launch for the whole batch: XCD teams keep the intermediate in L2
+// one persistent launch for the whole batch: XCD teams keep the intermediate in their L2 (wrp_fused.h)
 int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, hipStream_t st,
                  unsigned long long *d_stamps = nullptr)
 {
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
-#define WRP_FUSED(TC, TAPS)                                                                                            \
-    hipLaunchKernelGGL((wrp::fused_sector_1024x512<TC, TAPS>), dim3(h->n_cus * wrp::FusedGeom<TC>::WG_PER_CU),       \
-                       dim3(wrp::FusedGeom<TC>::THREADS), wrp::FusedGeom<TC>::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, \
-                       h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps, c.k_range_resolution, c.k_calibration, \
-                       d_stamps)
-#define WRP_ROLES(TAPS, AUX)                                                                                           \
-    hipLaunchKernelGGL((wrp::fused_roles_1024x512<TAPS, AUX>), dim3(h->n_cus * 2), dim3(wrp::FusedRoles::THREADS),   \
-                       wrp::FusedRoles::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors,   \
+#define WRP_FUSED(TAPS, POLL, STAMPS)                                                                                 \
+    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, POLL, STAMPS>), dim3(h->n_cus * 2), dim3(wrp::FUSED_THREADS), \
+                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
-#define WRP_F64(TAPS)                                                                                                  \
-    hipLaunchKernelGGL((wrp::fused64_1024x512<TAPS>), dim3(h->n_cus * 2), dim3(wrp::F64::THREADS), wrp::F64::LDS_BYTES, \
-                       st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,        \
-                       c.k_range_resolution, c.k_calibration, d_stamps)
-    if (h->fused_tcols == 8 && h->fused64) {   // tile + row workgroups of 1024 threads, 8 waves per SIMD
-        if (h->taps_pad == 7) WRP_F64(7); else WRP_F64(9);
-    } else
-    if (h->fused_tcols == 8) {          // tile workgroups + row workgroups, two per CU
-        if (h->fused_in_aux == 0) { if (h->taps_pad == 7) WRP_ROLES(7, 0); else WRP_ROLES(9, 0); }
-        else { if (h->taps_pad == 7) WRP_ROLES(7, 2); else WRP_ROLES(9, 2); }
-    } else {                            // one 1024-thread workgroup per CU doing both in rounds
-        if (h->taps_pad == 7) WRP_FUSED(16, 7); else WRP_FUSED(16, 9);
+    if (d_stamps) {
+        if (h->taps_pad == 7) WRP_FUSED(7, 0, true); else WRP_FUSED(9, 0, true);
+    } else if (h->fused_poll_load) {
+        if (h->taps_pad == 7) WRP_FUSED(7, 1, false); else WRP_FUSED(9, 1, false);
+    } else {
+        if (h->taps_pad == 7) WRP_FUSED(7, 0, false); else WRP_FUSED(9, 0, false);
     }
-#undef WRP_F64
-#undef WRP_ROLES
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(h->h_timeout, &h->d_ctl->timeout, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    // the status word of this launch lands in its own pinned slot; looked at by check_fused()
+    HIP_TRY(h, hipMemcpyAsync(&h->h_status[h->fused_launches % 64], &h->d_ctl->status, sizeof(unsigned),
+                              hipMemcpyDeviceToHost, st));
+    h->fused_launches++;
     return WRP_OK;
+}
+
+// Outcome of the fused launches issued so far whose stream work has completed (the caller has
+// synchronised, or we do).  A failure (bounded spin gave up, or the CUs did not host 32 + 32
+// workgroups per XCD) switches the handle to the two-kernel path and is reported ONCE.
+int check_fused(wrp_engine *h)
+{
+    if (h->fused_launches == 0) return WRP_OK;
+    unsigned bad = 0;
+    for (int k = 0; k < 64; k++) { bad |= h->h_status[k]; h->h_status[k] = 0; }
+    h->fused_launches = 0;
+    if (!bad) return WRP_OK;
+    h->fused = false;
+    h->hip_err = (bad & 2) ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; handle switched to the two-kernel path"
+                           : "fused launch: a bounded wait gave up (workgroups not co-resident?); handle switched to the two-kernel path";
+    return WRP_ERR_HIP;
 }
 
 int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
@@ -285,18 +285,11 @@ int destroy_impl(wrp_engine *h)
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->st_range) { (void)hipStreamSynchronize(h->st_range); (void)hipStreamDestroy(h->st_range); }
-    if (h->st_dopp) { (void)hipStreamSynchronize(h->st_dopp); (void)hipStreamDestroy(h->st_dopp); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int b = 0; b < 2; b++) {
-        if (h->ev_range[b]) (void)hipEventDestroy(h->ev_range[b]);
-        if (h->ev_dopp[b]) (void)hipEventDestroy(h->ev_dopp[b]);
-    }
-    if (h->d_mid2) (void)hipFree(h->d_mid2);
+    if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->d_mid) (void)hipFree(h->d_mid);
     if (h->d_ctl) (void)hipFree(h->d_ctl);
     if (h->d_mid_pool) (void)hipFree(h->d_mid_pool);
-    if (h->h_timeout) (void)hipHostFree(h->h_timeout);
+    if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->d_dump) (void)hipFree(h->d_dump);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->d_wr) (void)hipFree(h->d_wr);
@@ -314,7 +307,8 @@ int create_impl(wrp_engine *h)
     // up to 144 KiB of dynamic LDS for the range pass
     h->range_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // default chosen below
     h->tuned = shape_tuned(c.m, c.n);
-    h->fused = h->tuned && (c.flags & WRP_FLAG_FUSED) != 0;
+    // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
+    h->fused = h->tuned && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
     if ((c.flags & 0xff) == 0) h->range_tcols = h->persist ? 16 : 8;   // best measured tile for each form
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024_persistent<8>),
@@ -330,29 +324,18 @@ int create_impl(wrp_engine *h)
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
         h->n_cus = prop.multiProcessorCount;
     }
-    h->fused_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // tile + row workgroups unless 16 is asked for
-    if (const char *e = getenv("WRP_FUSED_IN_AUX")) h->fused_in_aux = atoi(e) ? 2 : 0;
-    if (const char *e = getenv("WRP_FUSED64")) h->fused64 = atoi(e) != 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused64_1024x512<7>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::F64::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused64_1024x512<9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::F64::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<7, 0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<9, 0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<7, 2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_roles_1024x512<9, 2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedRoles::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<16, 7>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<16>::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_sector_1024x512<16, 9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedGeom<16>::LDS_BYTES));
+    h->fused_poll_load = (c.flags & WRP_FLAG_FUSED_POLL_LOAD) != 0;
+#define WRP_FUSED_ATTR(TAPS, POLL, STAMPS)                                                                      \
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<TAPS, POLL, STAMPS>), \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES))
+    WRP_FUSED_ATTR(7, 0, false); WRP_FUSED_ATTR(9, 0, false);
+    WRP_FUSED_ATTR(7, 1, false); WRP_FUSED_ATTR(9, 1, false);
+    WRP_FUSED_ATTR(7, 0, true);  WRP_FUSED_ATTR(9, 0, true);
+#undef WRP_FUSED_ATTR
     HIP_TRY(h, hipMalloc(&h->d_ctl, sizeof(wrp::FusedCtl)));
     HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8));
-    HIP_TRY(h, hipHostMalloc(&h->h_timeout, sizeof(unsigned), hipHostMallocDefault));
-    *h->h_timeout = 0;
+    HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * 64, hipHostMallocDefault));
+    std::memset(h->h_status, 0, sizeof(unsigned) * 64);
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<16>::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, true>),
@@ -386,17 +369,7 @@ int create_impl(wrp_engine *h)
     // (measured 4.4 -> 3.8 -> 3.6 us/sector at 24 / 120 / 360); the 1.4 GiB workspace is 0.5 % of HBM
     h->max_batch = c.max_batch > 0 ? c.max_batch : 360;
     HIP_TRY(h, hipMalloc(&h->d_mid, sizeof(float2) * mid_elems(c) * h->max_batch));
-    h->overlap = h->tuned && (c.flags & WRP_FLAG_OVERLAP) != 0;
-    if (h->overlap) {
-        HIP_TRY(h, hipMalloc(&h->d_mid2, sizeof(float2) * mid_elems(c) * h->max_batch));
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->st_range, hipStreamNonBlocking));
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->st_dopp, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int b = 0; b < 2; b++) {
-            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_range[b], hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_dopp[b], hipEventDisableTiming));
-        }
-    }
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_batch, hipEventDisableTiming));
 
     const size_t table = (size_t)c.n_elevations * c.n_sectors * (c.m / 2) * 2;
     HIP_TRY(h, hipHostMalloc(&h->h_result, sizeof(float) * table, hipHostMallocDefault));
@@ -441,7 +414,8 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_OVERLAP | WRP_FLAG_ONE_TILE_PER_BLOCK)) != 0 || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
+        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_FUSED_POLL_LOAD)) != 0 ||
+        ((cfg->flags & WRP_FLAG_FUSED) && (cfg->flags & WRP_FLAG_TWO_KERNELS)) || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -565,38 +539,36 @@ int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, floa
 {
     if (!h || !d_iq || !d_out || n_sectors < 0) return WRP_ERR_INVALID;
     if (n_sectors == 0) return WRP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const wrp_config &c = h->cfg;
     const float2 *in = (const float2 *)d_iq;
-    if (h->fused && n_sectors >= 8) return launch_fused(h, in, n_sectors, d_out, st);
-    if (h->overlap && n_sectors > h->max_batch) {
-        // software pipeline over chunks: the range pass of chunk k+1 (HBM-bound) runs beside the
-        // Doppler pass of chunk k (VALU-bound) on two internal streams; two mid buffers.
-        HIP_TRY(h, hipEventRecord(h->ev_fork, st));
-        HIP_TRY(h, hipStreamWaitEvent(h->st_range, h->ev_fork, 0));
-        HIP_TRY(h, hipStreamWaitEvent(h->st_dopp, h->ev_fork, 0));
-        int k = 0;
-        for (int s0 = 0; s0 < n_sectors; s0 += h->max_batch, k++) {
-            const int cnt = std::min(h->max_batch, n_sectors - s0), b = k & 1;
-            float2 *mid = b ? h->d_mid2 : h->d_mid;
-            if (k >= 2) HIP_TRY(h, hipStreamWaitEvent(h->st_range, h->ev_dopp[b], 0));   // buffer b is free again
-            launch_range(h, in + (size_t)s0 * sector_elems(c), cnt, mid, h->st_range, nullptr);
-            HIP_TRY(h, hipEventRecord(h->ev_range[b], h->st_range));
-            HIP_TRY(h, hipStreamWaitEvent(h->st_dopp, h->ev_range[b], 0));
-            launch_doppler(h, mid, cnt, d_out + (size_t)s0 * (c.m / 2) * 2, h->st_dopp, nullptr);
-            HIP_TRY(h, hipEventRecord(h->ev_dopp[b], h->st_dopp));
-        }
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_dopp[(k - 1) & 1], 0));   // the last Doppler pass ends the batch
-        return WRP_OK;
-    }
-    for (int s0 = 0; s0 < n_sectors; s0 += h->max_batch) {
-        const int cnt = std::min(h->max_batch, n_sectors - s0);
-        int rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid,
+    // ONE batch in flight per handle: the workspace (intermediate, team buffers, control block) is
+    // shared, so a batch on another stream first waits for the previous batch (free on one stream)
+    if (h->batch_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_batch, 0));
+    int rc = WRP_OK;
+    if (h->fused && n_sectors >= WRP_FUSED_MIN_SECTORS) {
+        rc = launch_fused(h, in, n_sectors, d_out, st);
+    } else {
+        for (int s0 = 0; s0 < n_sectors && rc == WRP_OK; s0 += h->max_batch) {
+            const int cnt = std::min(h->max_batch, n_sectors - s0);
+            rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid,
                               d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
-        if (rc != WRP_OK) return rc;
+        }
     }
+    if (rc != WRP_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_batch, st));
+    h->batch_pending = true;
     return WRP_OK;
+}
+
+int wrp_check(wrp_handle h)
+{
+    if (!h) return WRP_ERR_INVALID;
+    if (h->fused_launches == 0) return WRP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->batch_pending) HIP_TRY(h, hipEventSynchronize(h->ev_batch));
+    return check_fused(h);
 }
 
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream)
@@ -625,9 +597,11 @@ int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *ou
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (e != hipSuccess) { h->hip_err = hipGetErrorString(e); return WRP_ERR_HIP; }
-    if (rc == WRP_OK && h->fused && *h->h_timeout) {
-        h->hip_err = "fused launch: a team barrier timed out (workgroups not co-resident?)";
-        return WRP_ERR_HIP;
+    if (rc == WRP_OK && check_fused(h) != WRP_OK) {
+        // the handle now runs the two-kernel path: compute this batch again (hip_err keeps the note)
+        const std::string note = h->hip_err;
+        rc = wrp_process_host(h, iq_host, n_sectors, out_host);
+        h->hip_err = note;
     }
     return rc;
 }
@@ -685,7 +659,14 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
-    if (ms_range || ms_doppler) {
+    {
+        const int frc = check_fused(h);
+        if (frc != WRP_OK) return frc;
+    }
+    if ((ms_range || ms_doppler) && h->fused && n_sectors >= WRP_FUSED_MIN_SECTORS) {
+        if (ms_range) *ms_range = 0.f;      // one launch: there is no split to report
+        if (ms_doppler) *ms_doppler = 0.f;
+    } else if (ms_range || ms_doppler) {
         // second run: one event pair per launch (adds event overhead, so it is kept out of ms_total)
         const wrp_config &c = h->cfg;
         float tr = 0.f, td = 0.f;
@@ -723,17 +704,19 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
                            unsigned long long *host_stamps, size_t host_count)
 {
     if (!h || !d_iq || !d_out || !host_stamps || n_sectors <= 0) return WRP_ERR_INVALID;
-    const size_t count = (size_t)h->n_cus * (h->fused_tcols == 8 ? 2 : 1) * wrp::FUSED_STAMP_TASKS * 8;   // per workgroup
+    if (!h->tuned) return WRP_ERR_UNSUPPORTED;   // the fused launch exists for 1024 x 512 only
+    const size_t count = (size_t)h->n_cus * 2 * wrp::FUSED_STAMP_TASKS * wrp::FUSED_STAMPS;
     if (host_count < count) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long *d = nullptr;
     HIP_TRY(h, hipMalloc(&d, count * 8));
-    (void)hipMemsetAsync(d, 0, count * 8, h->stream);
-    int rc = launch_fused(h, (const float2 *)d_iq, n_sectors, d_out, h->stream, d);
-    hipError_t e = hipMemcpyAsync(host_stamps, d, count * 8, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipMemsetAsync(d, 0, count * 8, h->stream);
+    int rc = e == hipSuccess ? launch_fused(h, (const float2 *)d_iq, n_sectors, d_out, h->stream, d) : WRP_ERR_HIP;
+    if (e == hipSuccess) e = hipMemcpyAsync(host_stamps, d, count * 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d);
     if (e != hipSuccess) { h->hip_err = hipGetErrorString(e); return WRP_ERR_HIP; }
+    if (rc == WRP_OK) rc = check_fused(h);
     return rc;
 }
 

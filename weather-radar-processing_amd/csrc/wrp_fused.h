@@ -1,52 +1,46 @@
-// wrp_fused.h -- fused persistent launch: both passes in ONE launch, the 2 MiB intermediate of a
-// sector-channel stays in an XCD's L2 (ONE buffer per XCD: two of them plus the streaming input
-// were measured to thrash the 4 MiB L2 -- every row then came back over the fabric; and the input
-// is read with non-temporal loads, or it pushes the buffer out all the same).
+// wrp_fused.h -- the whole per-sector chain (a2 .. a9) in ONE persistent launch.  The half-height
+// intermediate of a sector-channel (2 MiB) never goes to HBM: it is handed from the range FFT to
+// the Doppler rows through the L2 of the XCD whose 32 CUs work on that sector-channel.
 //
-// Geometry, from the tile width TCOLS (8 or 16 columns):
-//   workgroup = 64 TCOLS threads (TCOLS waves); tiles per channel-task = 512 / TCOLS = members at
-//   work per team; rows per member and task = TCOLS (one per wave).
-//   TCOLS = 16: one 1024-thread workgroup per CU (the form the engine launches).  TCOLS = 8: two
-//   512-thread workgroups per CU (80 KiB of LDS each); measured slower (5.9 vs 3.9 us/sector: the
-//   range stages are latency-bound per wave) and not wired to a flag -- the engine's
-//   8-column fused launch is wrp_fused_roles.h, which shares the device functions below.
-// At start every workgroup reads the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never
-// assumed), registers with that XCD's team and the grid meets once.  Team e owns sectors e,
-// e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...; member r owns range tile r and the
-// Doppler rows TCOLS r .. TCOLS r + TCOLS - 1 of every task.  The work is software-pipelined so that
-// neither hand-off is waited for right after it is produced.  Round t of a workgroup:
-//     S(t)   stages 1-3 of its tile of task t; the 4 output float4 per lane STAY IN REGISTERS
-//     B(t-1) its rows of task t-1: needs every tile of t-1 stored      (counter `stored`, counted
-//            by the members during their S(t) -- a stage of arithmetic ago)
-//     W(t)   store the tile of task t into the team's buffer: needs every row of t-1 loaded
-//            (counter `loaded`, counted by each wave when its row has arrived -- a row transform ago)
-// Both dependencies point backwards and every workgroup walks the rounds in order, so the
-// workgroup that is furthest behind can always run: no cycle.  Latency hiding:
-//   * a counter is read by one lane while the other waves still compute, and only if it was not
-//     yet satisfied does the workgroup fall into the (bounded) polling loop;
-//   * the tile stores drain while the next round's stage 1 computes; their count is added at that
-//     stage's barrier -- except that a workgroup never polls with an unsent count (it flushes
-//     first), which keeps the no-cycle argument valid;
-//   * the next tile is requested right after stage 1 has consumed the current one, a whole round
-//     before it is needed.
-// All spins are bounded and a timeout is reported.  Cache behaviour, all measured on MI355X
-// (tools/l2handoff.hip, FETCH_SIZE / WRITE_SIZE): tiles are stored with plain stores and stay in
-// the XCD's L2; rows are read with sc1 loads, which miss the reader's L1 (an sc0 load does not) and
-// are served by that L2 at 1.5 TB/s per XCD; team counters are L2 atomics of workgroup scope (no
-// sc1), read back with an atomic add of 0.  HH row sums wait in a register for the VV task of the
-// same gate (same wave, next round).
+// Reference being replaced: rpv2.cu:409-570 (about 14 passes over a 2-4 MiB array per channel).
 //
-// Range FFT: 1024 = 8 x 16 x 8, in-place DIF over positions p of a column:
-//   stage 1 (registers, from the prefetch): lane owns rows p0 + 128 r, r < 8, of two columns
-//           -> radix 8, twiddle W_1024^{p0 k1}, to LDS position k1*128 + p0
-//   stage 2 (LDS, one column per lane, b64): positions k1*128 + p1 + 8 r, r < 16 -> radix 16,
-//           twiddle W_128^{p1 k2}, in place
-//   stage 3 (LDS, column pair per lane, b128): positions k1*128 + k2*8 + r, r < 8 -> radix 8;
-//           gate k = k1 + 8 k2 + 128 k3, k3 < 4 kept.
-// Same padded LDS image as range_pass_1024<TCOLS> (RangeTile<TCOLS>), twiddles in its padding.
-// Arithmetic differs from the two-kernel path only in the factorisation of the range FFT
-// (8x16x8 instead of 16x8x8), so results agree to rounding, not bit for bit; the 8- and the
-// 16-column geometry perform identical arithmetic per element and agree bit for bit.
+// Why this shape (all measured on MI355X):
+//   * the two-kernel path moves 16.8 MB per sector (8 in, 4 out, 4 back in) and runs at the
+//     transport floor of that traffic (3.4 us; tools/ringbench.hip R = 360);
+//   * keeping the intermediate in a short ring that stays inside the 256 MiB Infinity Cache still
+//     costs 2.6 us per sector: what counts is bytes between an XCD and the fabric, not HBM hits;
+//   * input alone streams at 1.4 us per sector, so only an exchange INSIDE an XCD can get there.
+//
+// Launch: 2 x CUs workgroups of 512 threads; every CU hosts two (76 KiB of LDS each, <= 128 VGPRs).
+// At start a workgroup reads the XCD and the CU it runs on (HW_REG_XCC_ID, HW_REG_HW_ID: placement
+// is READ, never assumed): the first workgroup to arrive on a CU becomes a TILE workgroup, the
+// second a ROW workgroup, so that every CU always has the HBM-bound / barrier-bound range stages of
+// one beside the VALU-bound row transforms of the other.  The workgroups of one XCD form a team of
+// 32 tile members + 32 row members; the grid meets once (census), then the teams never talk to each
+// other.  Team e owns sectors e, e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...
+//   tile member r : range tile r (columns 16 r ..) of every task  -> the team's ONE 2 MiB buffer
+//   row member r  : gates 16 r .. 16 r + 15 of every task (wave w: gates 16 r + 2 w, + 1), a4 .. a9
+// Hand-offs (one buffer, so both directions):
+//   stored : tile members count a task's tile once its stores have drained; row members wait for 32
+//   loaded : row members count once their 16 rows are in registers; tile members wait for 32 before
+//            they overwrite the buffer with the next task's tile
+// Each counter exists in 32 replicas on lines of their own; a signalling workgroup adds to all 32
+// with ONE wave instruction and every waiter polls only ITS replica (32 workgroups polling one line
+// took 2.7 us to notice a count in round 1).  Counters are monotonic over tasks.  All of this stays
+// inside one XCD, whose L2 is the point of coherence for its own CUs: tiles are stored with plain
+// stores (the lines stay in that L2) and drained with s_waitcnt vmcnt(0) before the count; rows and
+// counters are read with loads that miss the reader's L1 (sc1).  The input is read non-temporally so
+// that it does not push the buffer out of the L2.  Every spin is bounded; a timeout or a team that
+// is not 32 + 32 is reported in FusedCtl::status and the engine falls back to the two-kernel path.
+//
+// Range FFT: exactly the arithmetic of range_pass_1024<16> (1024 = 16 x 8 x 8, same butterflies,
+// same twiddles, same order -> bit-identical results; the library is built with -ffp-contract=off
+// and every fused multiply-add is spelled out).  What differs is the LDS image: the sixteen 64-point
+// sub-transforms that follow the radix-16 stage are independent, and sub-transform k1 lives
+// entirely in wave k1 mod 8 for stages 2 and 3.  So the tile goes through LDS in two GROUPS of
+// eight k1 (72 KiB instead of 144 KiB -- which is what lets two workgroups share a CU with
+// 16-column tiles, i.e. whole 128-byte lines); group 1 waits in 32 registers meanwhile, and only
+// the hand-over from stage 1 needs workgroup barriers (4 per tile).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -54,42 +48,40 @@
 
 namespace wrp {
 
-constexpr int FUSED_RING = 8;   // completion counters are a ring over tasks (at most 2 tasks are in flight)
-struct FusedCtl {               // zeroed by hipMemsetAsync before every launch; every counter on its own 64-byte line
-    unsigned census[8];         // workgroups per XCC
-    unsigned arrived;           // grid-wide start counter
-    unsigned timeout;           // 1: a bounded spin gave up; 2: a team has too few workgroups
-    unsigned pad[6];
-    unsigned stored[8][FUSED_RING][16];     // tiles of task q stored: slot q % RING, target ITEMS * (q / RING + 1)
-    unsigned loaded[8][FUSED_RING][16];     // rows of task q in registers: target 512 * (q / RING + 1)
-    unsigned census_rows[8];                // fused_roles: row workgroups per XCC (census[] counts the tile workgroups)
-    unsigned cu_arrivals[8][256];           // fused64: workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
-};
+constexpr int FUSED_THREADS = 512;
+constexpr int FUSED_MEMBERS = 32;                  // tile members = row members per team = CUs per XCD
 constexpr int FUSED_STAMP_TASKS = 16;
-constexpr size_t FUSED_MID_ELEMS = (size_t)(RP_M / 2) * DP_N;              // one channel
-constexpr size_t FUSED_TEAM_ELEMS = FUSED_MID_ELEMS;                       // per team: ONE mid buffer (float2 units)
+constexpr int FUSED_STAMPS = 8;
+constexpr size_t FUSED_TEAM_ELEMS = (size_t)(RP_M / 2) * DP_N;   // float2 units: ONE mid[512][512] per team
 
-template <int TCOLS>
-struct FusedGeom {
-    typedef RangeTile<TCOLS> FT;
-    static constexpr int CP = TCOLS / 2;                  // column pairs
-    static constexpr int WAVES = TCOLS;
-    static constexpr int THREADS = 64 * WAVES;            // 1024 / 512
-    static constexpr int ITEMS = DP_N / TCOLS;            // tiles per task = members at work per team: 32 / 64
-    static constexpr int WG_PER_CU = 16 / TCOLS;          // 1 / 2
-    // LDS: image (twiddles in its pads) | window wr_c[1024] | Doppler twiddles [512], whose entries
-    // 448.. are never read (largest index used: 63 * 7 = 441) and hold the control words
-    static constexpr int OFF_TWN = FT::LDS_BYTES;
-    static constexpr int OFF_CTL = OFF_TWN + 448 * 8;
-    static constexpr int LDS_BYTES = OFF_TWN + DP_N * 8;  // 155648 / 81920 = exactly half of the CU's 160 KiB
-    // the row buffers (one per wave) alias the image from block 0; they overwrite the twiddle pads of
-    // those blocks unless the twiddles live above them (16 columns), else the pads are re-filled
-    static constexpr int ROW_BLOCKS = WAVES * DP_ELEMS * 8 / FT::BLK_BYTES;
-    static constexpr bool TW_CLOBBERED = FT::TW_BLK0 < ROW_BLOCKS;
-    static constexpr int TW_LOST = TW_CLOBBERED ? ROW_BLOCKS * FT::TW_PER_PAD : 0;   // entries 0 .. TW_LOST-1
-    static_assert(WAVES * DP_ELEMS * 8 % FT::BLK_BYTES == 0, "row buffers end on a block boundary");
-    static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "fused launch exceeds the CU's LDS");
-    static_assert(TW_LOST <= THREADS, "one twiddle per thread is re-filled");
+struct FusedLine { unsigned w; unsigned pad[31]; };   // one counter per 128-byte line
+struct FusedCtl {               // zeroed by hipMemsetAsync before every launch
+    unsigned arrived;           // grid-wide start counter
+    unsigned status;            // 0 ok; 1: a bounded spin gave up; 2: a team is not 32 + 32 workgroups
+    unsigned pad0[30];
+    unsigned census[2][8];      // workgroups per kind (0 tile, 1 row) and XCC
+    unsigned pad1[16];
+    unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
+    FusedLine stored[8][FUSED_MEMBERS];      // [xcc][replica r]: tiles stored so far; polled by row member r only
+    FusedLine loaded[8][FUSED_MEMBERS];      // [xcc][replica r]: row sets loaded so far; polled by tile member r only
+};
+static_assert(sizeof(FusedCtl) % 16 == 0, "memset block is a multiple of 16 bytes");
+
+// LDS of a tile workgroup: image of ONE k1-group [8 k1][64 positions][16 columns] complex, one
+// position (128 B) of padding after every 8 -> all three stages are bank-conflict free (same map
+// as RangeTile<16>); the 1024-entry twiddle table lives in the 64 pads; window behind the image.
+struct FusedTile {
+    static constexpr int ROW_BYTES = 128, BLK_BYTES = 9 * ROW_BYTES, BLOCKS = 64;
+    static constexpr int IMG_BYTES = BLOCKS * BLK_BYTES;         // 73728
+    static constexpr int OFF_WR = IMG_BYTES;                     // float wr_c[1024]
+    static constexpr int OFF_CTL = OFF_WR + RP_M * 4;            // 77824: control words, both kinds
+    static constexpr int LDS_BYTES = OFF_CTL + 64;               // 77888 -> exactly two workgroups per CU
+    // row workgroup: 8 wave buffers, then the Doppler twiddles
+    static constexpr int OFF_TWN = 8 * DP_ELEMS * 8;             // 36864
+    static_assert(OFF_TWN + DP_N * 8 <= OFF_CTL, "row workgroup layout fits");
+    static_assert(2 * LDS_BYTES <= 160 * 1024 && 3 * LDS_BYTES > 160 * 1024, "exactly two workgroups per CU");
+    static __device__ __forceinline__ int addr(int pos, int cp) { return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + cp * 16; }
+    static __device__ __forceinline__ int tw_addr(int e) { return (e >> 4) * BLK_BYTES + 8 * ROW_BYTES + (e & 15) * 8; }
 };
 
 __device__ __forceinline__ unsigned xcc_id()
@@ -98,317 +90,312 @@ __device__ __forceinline__ unsigned xcc_id()
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 7;
 }
+__device__ __forceinline__ unsigned hw_cu_key()   // se, sh, cu of the CU this wave runs on
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    return (v >> 8) & 0xff;
+}
 
-// Team counters live in the XCD's L2 and are only ever touched by that XCD's workgroups, so they
-// need no coherence beyond it: additions are plain L2 atomics (workgroup scope, no sc1).
+// Team counters are only ever touched by workgroups of ONE XCD, whose L2 performs every atomic:
+// additions are plain L2 atomics (workgroup scope, no sc1, the line stays in that L2).
 __device__ __forceinline__ void l2_count(unsigned *p)
 {
     __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// POLL = 0: an atomic add of 0 with return (performed at the L2; the zero is hidden from the
+// compiler, which otherwise folds the idempotent atomic into an sc0 load that hits the stale L1);
+// POLL = 1: a device-scope load (sc1: misses the L1, served by the L2).
+template <int POLL>
 __device__ __forceinline__ unsigned l2_peek(unsigned *p)
 {
-    // An atomic add of 0 with return: performed at the L2 like every atomic, so it cannot hit a stale
-    // line of the CU's L1.  The zero is hidden from the compiler, which otherwise folds the idempotent
-    // atomic into an sc0 load.  Every alternative was measured worse on MI355X (the rounds launch of
-    // this file, us/sector): sc0 load -- never sees the count (stale L1 line); device-scope (sc1) load
-    // 5.7; non-temporal load 7.2 (sees it late); this 3.9.  Its weakness: dozens of workgroups polling
-    // ONE line serialise in the L2's atomic unit (2.7 us median, 4.8 us worst, to notice a count in the
-    // tile/row launches, where 32 workgroups poll for most of a task) -- poll rarely, or per-waiter lines.
-    unsigned zero = 0;
-    asm volatile("" : "+v"(zero));
-    return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (POLL == 0) {
+        unsigned zero = 0;
+        asm volatile("" : "+v"(zero));
+        return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // control words in LDS: address space 3 spelled out, because hipcc does not infer it for volatile
 // accesses and would emit flat instructions with sc0 sc1 for them
 typedef __attribute__((address_space(3))) volatile int lds_word;
 
-// every thread calls; thread 0 polls; false = timed out.  TEAM: the counter is a team counter (see above),
-// otherwise it is shared by the whole grid and read at device scope.
-template <bool TEAM>
-__device__ __forceinline__ bool team_wait_ge(unsigned *p, unsigned target, unsigned *tmo, lds_word *s_ok)
+// thread 0 of the workgroup: wait until *p >= target; false = gave up (status set)
+template <int POLL>
+__device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *status)
 {
-    if (threadIdx.x == 0) {
-        int good = 0;
 #pragma unroll 1
-        for (unsigned spins = 0; spins < (1u << 21); spins++) {
-            const unsigned now = TEAM ? l2_peek(p) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (now >= target) { good = 1; break; }
-            if ((spins & 63) == 63 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!good) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_ok = good;
+    for (unsigned spins = 0; spins < (1u << 22); spins++) {
+        if (l2_peek<POLL>(p) >= target) return true;
+        if ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
     }
-    __syncthreads();
-    const bool ok = *s_ok != 0;
-    __syncthreads();
-    return ok;
+    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
 }
 
-// this lane's 8 row loads (rows p0 + 128 r of one column pair) + its two Doppler-window values;
-// valid = false -> zero-record descriptor, all loads dropped (see range_load)
-template <int TCOLS, int AUX = StreamAux<TCOLS>::value>
-__device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-uniform */, int n, int col_base, const float *wd,
-                                                float4 (&v)[8], float2 &wdv, bool valid)
+// ---- tile member: device functions -----------------------------------------------------------
+// this lane's 16 row loads (rows p0 + 64 r of one column pair) + its two Doppler-window values;
+// valid = false -> zero-record descriptor, the hardware drops the loads (see range_load)
+__device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
+                                                float4 (&v)[16], float2 &wdv, bool valid)
 {
-    typedef FusedGeom<TCOLS> G;
     const int w = wave_id();
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));   // recompute the lane offsets per call instead of keeping (spilling) them
-    const int p0 = w * (64 / G::CP) + l / G::CP, cp = l % G::CP;
-    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * n * 8u : 0u);
-    const int voff = (p0 * n + col_base + cp * 2) * 8;
+    const int p0 = w * 8 + (l >> 3), cp = l & 7;
+    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
+    const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
 #pragma unroll
-    // non-temporal: the input streams through the L2 once and must not push the team's buffer out of it
-    for (int r = 0; r < 8; r++) v[r] = buf_load_f4<AUX>(rs, voff, 128 * r * n * 8);
-    wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)n * 4u), (col_base + cp * 2) * 4, 0);
+    for (int r = 0; r < 16; r++) v[r] = buf_load_f4<AUX_NT>(rs, voff, 64 * r * DP_N * 8);
+    wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
-template <int TCOLS, class Hook0, class Hook>
-__device__ __forceinline__ void fused_stage12(unsigned char *smem, float4 (&v)[8], float2 wdv, Hook0 before_barrier1,
-                                              Hook after_stage1)
+// stage 1 (a2 + first radix of a3): window, radix 16 over rows p0 + 64 r, twiddle W_1024^{p0 k1};
+// k1 < 8 goes to the LDS image (group 0), k1 >= 8 stays in ga / gc (group 1)
+__device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&ga)[8], cf (&gc)[8])
 {
-    typedef FusedGeom<TCOLS> G;
-    typedef typename G::FT FT;
+    typedef FusedTile T;
     int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));   // every per-lane LDS address below is recomputed per call, not hoisted + spilled
-    {   // ---- stage 1: radix 8 over rows p0 + 128 r, two columns per lane
-        const int w = tid >> 6, l = tid & 63, cp = l % G::CP;
-        const int p0 = w * (64 / G::CP) + l / G::CP;
-        const float *s_wr = reinterpret_cast<const float *>(smem + FT::OFF_WR);
-        cf a[8], c[8], t1[8];
+    asm volatile("" : "+v"(tid));   // per-lane LDS addresses are recomputed per tile, not hoisted + spilled
+    const int w = tid >> 6, l = tid & 63, cp = l & 7;
+    const int p0 = w * 8 + (l >> 3);
+    const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
+    cf a[16], c[16];
 #pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) t1[k1] = *reinterpret_cast<const float2 *>(smem + FT::tw_addr((p0 * k1) & (RP_M - 1)));
+    for (int r = 0; r < 16; r++) {
+        const float wrow = s_wr[p0 + 64 * r];
+        const float w0 = wrow * wdv.x, w1 = wrow * wdv.y;
+        a[r] = make_float2(v[r].x * w0, v[r].y * w0);
+        c[r] = make_float2(v[r].z * w1, v[r].w * w1);
+    }
+    fft16<-1>(a);
+    fft16<-1>(c);
+    *reinterpret_cast<float4 *>(smem + T::addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const float wrow = s_wr[p0 + 128 * r];
-            const float w0 = wrow * wdv.x, w1 = wrow * wdv.y;
-            a[r] = make_float2(v[r].x * w0, v[r].y * w0);
-            c[r] = make_float2(v[r].z * w1, v[r].w * w1);
-        }
+    for (int k1 = 1; k1 < 8; k1++) {
+        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
+        const cf x = cmul(a[k1], t), y = cmul(c[k1], t);
+        *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
+    }
+#pragma unroll
+    for (int k1 = 8; k1 < 16; k1++) {
+        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
+        ga[k1 - 8] = cmul(a[k1], t);
+        gc[k1 - 8] = cmul(c[k1], t);
+    }
+}
+
+// group 1 from its registers into the image (after group 0 has left it)
+__device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const cf (&ga)[8], const cf (&gc)[8])
+{
+    typedef FusedTile T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int w = tid >> 6, l = tid & 63, cp = l & 7;
+    const int p0 = w * 8 + (l >> 3);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        *reinterpret_cast<float4 *>(smem + T::addr(j * 64 + p0, cp)) = make_float4(ga[j].x, ga[j].y, gc[j].x, gc[j].y);
+}
+
+// stages 2 and 3 of the sub-transform this WAVE owns in the current group (image rows w*64 ..):
+// wave-private, no workgroup barrier in between.  ONE column per lane here (col = l & 15, two items
+// per lane and stage), which halves the registers of these stages -- the next tile's 64 registers
+// are in flight meanwhile -- and keeps every 8-byte LDS access conflict-free: a wave-instruction
+// covers 4 positions x 128 contiguous bytes.  Same arithmetic per element as range_stage12/3.
+// o[it][k3] = gate k1 + 16 k2 + 128 k3 (k2 = (l >> 4) + 4 it, k3 < 4) of column col; the chain
+// never reads the other half of the gates (rpv2.cu:502).
+__device__ __forceinline__ void fused_stage23(unsigned char *smem, cf (&o)[2][4])
+{
+    typedef FusedTile T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;   // position w*64 of this lane's column
+#pragma unroll
+    for (int it = 0; it < 2; it++) {   // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
+        const int p1 = (l >> 4) + 4 * it;
+        cf a[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
         fft8<-1>(a);
-        fft8<-1>(c);
-        *reinterpret_cast<float4 *>(smem + FT::addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
+        *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
 #pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) {
-            const cf x = cmul(a[k1], t1[k1]), y = cmul(c[k1], t1[k1]);
-            *reinterpret_cast<float4 *>(smem + FT::addr(k1 * 128 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
+        for (int k2 = 1; k2 < 8; k2++) {
+            const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((16 * p1 * k2) & (RP_M - 1)));
+            *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t);
         }
     }
-    before_barrier1();
-    __syncthreads();
-    after_stage1();   // v has been consumed: the next tile may be requested into it
-    {   // ---- stage 2: radix 16 over positions k1*128 + p1 + 8 r, ONE column per lane
-        const int col = tid % TCOLS, k1 = tid / (TCOLS * 8);
-        const int p1 = (tid / TCOLS) & 7;
-        unsigned char *base = smem + (col >> 1) * 16 + (col & 1) * 8;
-        cf x[16], t2[16];
+    wave_lds_fence();
 #pragma unroll
-        for (int k2 = 1; k2 < 16; k2++) t2[k2] = *reinterpret_cast<const float2 *>(smem + FT::tw_addr((8 * p1 * k2) & (RP_M - 1)));
+    for (int it = 0; it < 2; it++) {   // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
+        const int k2 = (l >> 4) + 4 * it;
+        cf a[8];
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = *reinterpret_cast<const float2 *>(base + FT::addr(k1 * 128 + p1 + 8 * r, 0));
-        fft16<-1>(x);
-        *reinterpret_cast<float2 *>(base + FT::addr(k1 * 128 + p1, 0)) = x[0];
+        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
+        fft8<-1>(a);
 #pragma unroll
-        for (int k2 = 1; k2 < 16; k2++)
-            *reinterpret_cast<float2 *>(base + FT::addr(k1 * 128 + p1 + 8 * k2, 0)) = cmul(x[k2], t2[k2]);
+        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
     }
-    __syncthreads();
 }
 
-// stage 3 in two halves: the arithmetic (outputs of gates k1 + 8 k2 + 128 k3, k3 < 4, of one column pair) ...
-template <int TCOLS>
-__device__ __forceinline__ void fused_stage3_compute(const unsigned char *smem, float4 (&o)[4])
+// the stores of one group: plain (the lines stay in the XCD's L2, where the row members find them);
+// 16 lanes x 8 bytes = one whole 128-byte line per gate
+__device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
 {
-    typedef FusedGeom<TCOLS> G;
-    typedef typename G::FT FT;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int cp = tid % G::CP, k1 = tid / (G::CP * 16), k2 = (tid / G::CP) & 15;
-    cf a[8], c[8];
+    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
+    const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const float4 u = *reinterpret_cast<const float4 *>(smem + FT::addr(k1 * 128 + k2 * 8 + r, cp));
-        a[r] = make_float2(u.x, u.y);
-        c[r] = make_float2(u.z, u.w);
-    }
-    fft8<-1>(a);
-    fft8<-1>(c);
+    for (int it = 0; it < 2; it++)
 #pragma unroll
-    for (int k3 = 0; k3 < 4; k3++) o[k3] = make_float4(a[k3].x, a[k3].y, c[k3].x, c[k3].y);
+        for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
+            v2f t;
+            t.x = o[it][k3].x; t.y = o[it][k3].y;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (64 * it + 128 * k3) * DP_N * 8, 0, 0);
+        }
 }
 
-// ... and the stores, which may happen much later
-template <int TCOLS, int AUX = 0>
-__device__ __forceinline__ void fused_stage3_store(float2 *dst /* wave-uniform */, int n, int col_base, const float4 (&o)[4])
-{
-    typedef FusedGeom<TCOLS> G;
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int cp = tid % G::CP, k1 = tid / (G::CP * 16), k2 = (tid / G::CP) & 15;
-    const rsrc_t rd = make_rsrc(dst, (unsigned)(RP_M / 2) * n * 8u);
-    const int voff = ((k1 + 8 * k2) * n + col_base + cp * 2) * 8;
-#pragma unroll
-    for (int k3 = 0; k3 < 4; k3++)   // gates < m/2 only; row offset in the VGPR (see buf_store_f4)
-        buf_store_f4<AUX>(rd, voff + 128 * k3 * n * 8, 0, o[k3]);
-}
-
-template <int TCOLS, int TAPS>
-// 4 waves per SIMD in both geometries (two 8-wave workgroups or one 16-wave workgroup per CU): 128 VGPRs
-__global__ __launch_bounds__(FusedGeom<TCOLS>::THREADS, 4) void fused_sector_1024x512(
+template <int TAPS, int POLL, bool STAMPS>
+__global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[512][512]
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
     float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
 {
-    typedef FusedGeom<TCOLS> G;
-    typedef typename G::FT FT;
+    typedef FusedTile T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lds_word *s_ctl = (lds_word *)(smem + G::OFF_CTL);
-    float2 *s_twn = reinterpret_cast<float2 *>(smem + G::OFF_TWN);
+    lds_word *s_ctl = (lds_word *)(smem + T::OFF_CTL);
     const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
     const int n = DP_N, gates = RP_M / 2;
-    const DumpPtrs nodump{};
-    for (int e = tid; e < 448; e += G::THREADS) s_twn[e] = tw_n[e];     // entries 448.. are the control words
-    for (int e = tid; e < RP_M; e += G::THREADS) {   // twiddle table into the image's padding, window behind the image
-        *reinterpret_cast<float2 *>(smem + FT::tw_addr(e)) = rc.tw[e];
-        reinterpret_cast<float *>(smem + FT::OFF_WR)[e] = rc.wr_c[e];
-    }
 
-    // ---- team formation -----------------------------------------------------------------
+    // ---- who am I: XCD, kind (first / second workgroup on this CU), rank inside the team --------
     if (tid == 0) {
         const unsigned x = xcc_id();
+        const unsigned a = atomicAdd(&ctl->cu_arrivals[x][hw_cu_key()], 1u);
+        const unsigned kind = a & 1u;
         s_ctl[1] = (int)x;
-        s_ctl[2] = (int)atomicAdd(&ctl->census[x], 1u);
+        s_ctl[2] = (int)kind;
+        s_ctl[3] = (int)atomicAdd(&ctl->census[kind][x], 1u);
         __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!team_wait_ge<false>(&ctl->arrived, gridDim.x, &ctl->timeout, &s_ctl[0])) return;
-    if (tid == 0) {
-        int teams = 0, trank = 0;
-        for (int x = 0; x < 8; x++) {
-            const unsigned c = __hip_atomic_load(&ctl->census[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c) { if (x < s_ctl[1]) trank++; teams++; }
-            if (x == s_ctl[1]) s_ctl[7] = (int)c;
+        // the grid meets once: afterwards the census is final
+        int good = 0;
+#pragma unroll 1
+        for (unsigned spins = 0; spins < (1u << 22); spins++) {
+            if (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { good = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
         }
+        int teams = 0, trank = 0;
+        for (unsigned y = 0; y < 8; y++) {
+            const unsigned ct = __hip_atomic_load(&ctl->census[0][y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned cr = __hip_atomic_load(&ctl->census[1][y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ct + cr == 0) continue;
+            if (ct < (unsigned)FUSED_MEMBERS || cr < (unsigned)FUSED_MEMBERS) good = good ? 2 : 0;   // a team that cannot work
+            if (y < x) trank++;
+            teams++;
+        }
+        if (good != 1) __hip_atomic_store(&ctl->status, good == 2 ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ctl[0] = good == 1;
         s_ctl[4] = teams;
         s_ctl[5] = trank;
     }
     __syncthreads();
+    if (!s_ctl[0]) return;
     // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
-    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]), kind = __builtin_amdgcn_readfirstlane(s_ctl[2]);
+    const int rank = __builtin_amdgcn_readfirstlane(s_ctl[3]);
     const int teams = __builtin_amdgcn_readfirstlane(s_ctl[4]), trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
-    const int rank = __builtin_amdgcn_readfirstlane(s_ctl[2]), sz = __builtin_amdgcn_readfirstlane(s_ctl[7]);
-    const int T = 2 * ((n_sectors - trank + teams - 1) / teams);             // channel-tasks of this team
+    if (rank >= FUSED_MEMBERS) return;   // surplus workgroups own nothing
+    const int tasks = 2 * ((n_sectors - trank + teams - 1) / teams);   // channel-tasks of this team
     float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
-    float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;   // aliases the image from block 0 (rows only)
-    if (sz < G::ITEMS) {               // the static schedule needs ITEMS members per team
-        if (tid == 0) __hip_atomic_store(&ctl->timeout, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (rank >= G::ITEMS) return;      // surplus members own nothing
-    const int col0 = rank * TCOLS, gate = rank * G::WAVES + w;
-
-    auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
-    auto counter = [&](unsigned (*arr)[FUSED_RING][16], int q) { return &arr[xcc][q % FUSED_RING][0]; };
-    auto turns = [&](int q) { return (unsigned)(q / FUSED_RING + 1); };
-    auto stamp = [&](int round, int k) {
-        if (stamps && tid == 0 && round < FUSED_STAMP_TASKS)
-            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + round) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    unsigned *my_stored = &ctl->stored[xcc][rank].w, *my_loaded = &ctl->loaded[xcc][rank].w;
+    auto stamp = [&](int q, int k) {
+        if (STAMPS && stamps && tid == 0 && q < FUSED_STAMP_TASKS)
+            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * FUSED_STAMPS + k] = __builtin_amdgcn_s_memrealtime();
     };
+    if (STAMPS && stamps && tid == 0)   // kind, xcc, rank in the last slot of task 0
+        stamps[(size_t)blockIdx.x * FUSED_STAMP_TASKS * FUSED_STAMPS + FUSED_STAMPS - 1] =
+            ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
 
-    unsigned *pend = nullptr;   // `stored` counter of the tile just written: its stores are still draining
-    // stores drained by every wave, then one lane counts; in front of every polling loop
-    auto flush = [&]() {
-        if (pend) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) l2_count(pend);
-            pend = nullptr;
+    if (kind == 0) {
+        // =============================== tile member ===============================
+        const int col0 = rank * 16;
+        auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
+        float4 v[16];
+        float2 wdv;
+        fused_tile_load(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);     // HBM requests first ...
+        for (int e = tid; e < RP_M; e += FUSED_THREADS) {                 // ... tables while they fly
+            *reinterpret_cast<float2 *>(smem + T::tw_addr(e)) = rc.tw[e];
+            reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
         }
-    };
-    int chk = 0;
-    // dependency `*p >= tgt`, of which lane 0 holds a recent value: one barrier when it was already
-    // satisfied, otherwise flush the unsent count and poll
-    auto resolve = [&](unsigned seen, unsigned *p, unsigned tgt) -> bool {
-        lds_word *slot = s_ctl + 8 + (chk++ & 3);
-        if (tid == 0) *slot = seen >= tgt;
         __syncthreads();
-        if (*slot) return true;
-        flush();
-        return team_wait_ge<true>(p, tgt, &ctl->timeout, &s_ctl[0]);
-    };
-
-    float4 v[8];         // this lane's share of the tile of the coming round
-    float2 wdv;
-    float s_hh = 0.f;    // HH row sum of this wave's gate, waiting for the VV task
-    fused_tile_load<TCOLS>(tile_src(0), n, col0, rc.wd, v, wdv, T > 0);
 #pragma unroll 1
-    for (int t = 0; t <= T; t++) {
-        float4 o[4];
-        unsigned seen = 0;
-        stamp(t, 0);
-        if (t < T) {
-            // ---------------- S(t): this member's tile of task t, outputs kept in registers ----------------
-            const float2 wcur = wdv;
-            if (stamps) {   // diagnostics only: when did the tile arrive
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                stamp(t, 1);
-            }
-            fused_stage12<TCOLS>(
-                smem, v, wcur,
-                [&]() {   // before the barrier after stage 1: the previous tile's stores have drained behind the arithmetic
-                    if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                },
-                [&]() {   // after it: count that tile, request the next one
-                    if (pend && tid == 0) l2_count(pend);
-                    pend = nullptr;
-                    fused_tile_load<TCOLS>(tile_src(t + 1 < T ? t + 1 : 0), n, col0, rc.wd, v, wdv, t + 1 < T);
-                });
-            stamp(t, 2);
-            if (t >= 1 && tid == 0) seen = l2_peek(counter(ctl->stored, t - 1));   // looked at after stage 3
-            fused_stage3_compute<TCOLS>(smem, o);
-        } else {
-            flush();   // last round: the last tile's count is still unsent
-            if (tid == 0) seen = l2_peek(counter(ctl->stored, t - 1));
+        for (int q = 0; q < tasks; q++) {
+            cf ga[8], gc[8];
+            cf o[2][4];
+            stamp(q, 0);
+            fused_stage1(smem, v, wdv, ga, gc);
+            __syncthreads();                    // A1: group 0 is in the image
+            stamp(q, 1);
+            fused_stage23(smem, o);
+            // the buffer still holds task q-1 until every row member has its rows in registers
+            if (tid == 0) s_ctl[8] = q == 0 || spin_ge<POLL>(my_loaded, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
+            __syncthreads();                    // A2: group 0 has left the image; verdict of the wait
+            if (!s_ctl[8]) return;
+            stamp(q, 2);
+            fused_store(mid, col0, 0, o);
+            fused_group1_to_lds(smem, ga, gc);
+            __syncthreads();                    // A3: group 1 is in the image
+            // v is free: request the next tile now, it flies during the rest of this one
+            fused_tile_load(tile_src(q + 1 < tasks ? q + 1 : 0), col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage23(smem, o);
+            fused_store(mid, col0, 1, o);
+            stamp(q, 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores are in the L2
+            __syncthreads();                    // A4: tile stored; image free for the next stage 1
+            if (w == 0 && l < FUSED_MEMBERS) l2_count(&ctl->stored[xcc][l].w);
+            stamp(q, 4);
         }
-        if (t >= 1) {
-            // ---------------- B(t-1): this member's rows of task t-1 ----------------
-            const int q = t - 1;
-            // every tile of the task stored (also the barrier that frees the image for the row buffers)
-            if (!resolve(seen, counter(ctl->stored, q), G::ITEMS * turns(q))) return;
-            stamp(t, 3);
-            cf x[8];
-            doppler_load_row<AUX_SC1>(mid + (size_t)gate * n, l, x);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row is in registers: the buffer may be overwritten
-            if (l == 0) l2_count(counter(ctl->loaded, q));
-            stamp(t, 4);
-            const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
-            stamp(t, 5);
-            if ((q & 1) == 0) s_hh = s;
-            else if (l == 0) reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh, s, k_rr, k_cal);
-        } else {
+    } else {
+        // =============================== row member ===============================
+        float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
+        float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
+        for (int e = tid; e < DP_N; e += FUSED_THREADS) s_twn[e] = tw_n[e];
+        const DumpPtrs nodump{};
+        const int g0 = rank * 16 + 2 * w;
+        float s_hh0 = 0.f, s_hh1 = 0.f;     // HH row sums of this wave's gates, waiting for the VV task
+#pragma unroll 1
+        for (int q = 0; q < tasks; q++) {
+            stamp(q, 0);
+            if (tid == 0) s_ctl[8] = spin_ge<POLL>(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status);
+            __syncthreads();                    // every tile of task q is in the buffer (and s_twn is filled)
+            if (!s_ctl[8]) return;
+            stamp(q, 1);
+            cf x0[8], x1[8];
+            doppler_load_row<AUX_SC1>(mid + (size_t)g0 * n, l, x0);
+            doppler_load_row<AUX_SC1>(mid + (size_t)(g0 + 1) * n, l, x1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the buffer may be overwritten
             __syncthreads();
-        }
-        if (t < T) {
-            // ---------------- W(t): store the tile; every row of task t-1 must have been loaded ----------------
-            if (t >= 1) {
-                if (tid == 0) seen = l2_peek(counter(ctl->loaded, t - 1));   // wave 0 is done first; the others still compute
-                if (!resolve(seen, counter(ctl->loaded, t - 1), DP_N * turns(t - 1))) return;
-                if (G::TW_CLOBBERED) {   // the row buffers have overwritten twiddle pads: re-fill them (L1/L2 hits) ...
-                    if (tid < G::TW_LOST) *reinterpret_cast<float2 *>(smem + FT::tw_addr(tid)) = rc.tw[tid];
-                }
+            if (w == 0 && l < FUSED_MEMBERS) l2_count(&ctl->loaded[xcc][l].w);
+            stamp(q, 2);
+            const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g0, false, nodump);
+            const float s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump);
+            stamp(q, 3);
+            if ((q & 1) == 0) {
+                s_hh0 = s0;
+                s_hh1 = s1;
+            } else if (l == 0) {
+                float *o2 = &out[((size_t)(trank + (q >> 1) * teams) * gates + g0) * 2];
+                reflectivity_store(o2, g0, s_hh0, s0, k_rr, k_cal);
+                reflectivity_store(o2 + 2, g0 + 1, s_hh1, s1, k_rr, k_cal);
             }
-            stamp(t, 6);
-            fused_stage3_store<TCOLS>(mid, n, col0, o);
-            pend = counter(ctl->stored, t);
-            if (G::TW_CLOBBERED) __syncthreads();   // ... before the next stage 1 reads them
         }
-        stamp(t, 7);
     }
-    flush();
 }
 
 } // namespace wrp
