@@ -12,7 +12,7 @@ PKG      := weather-radar-processing_amd
 CSRC     := $(PKG)/csrc
 HOST     := $(PKG)/host
 LIBDIR   := $(PKG)/lib
-HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=off
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=off -fno-slp-vectorize
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -Wall
 
 all: lib host oracle

@@ -80,8 +80,10 @@ typedef struct {
  * next tile while the current one is being transformed.  This flag selects the
  * one-tile-per-workgroup form instead (same arithmetic, bit-identical results; A/B only). */
 #define WRP_FLAG_ONE_TILE_PER_BLOCK 0x400
-/* tuning: the fused launch polls its team counters with device-scope loads instead of L2 atomics */
+/* tuning (A/B): the fused launch polls its team counters with scalar loads by default; these select
+ * device-scope vector loads or L2 atomics instead */
 #define WRP_FLAG_FUSED_POLL_LOAD 0x1000
+#define WRP_FLAG_FUSED_POLL_ATOMIC 0x2000
 
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
 typedef enum {
@@ -168,11 +170,9 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
                           int iters, float *ms_total, float *ms_range, float *ms_doppler);
 
 /* Diagnostics: one fused launch (a separate instantiation) with in-kernel phase stamps (100 MHz
- * ticks) copied to host_stamps[2 x CUs workgroups][16 tasks][8].  Slot 7 of task 0 identifies the
- * workgroup: kind << 32 | xcc << 16 | rank.  Tile workgroups (kind 0): 0 task start, 1 stage 1 done,
- * 2 group 0 transformed and the previous task's rows loaded, 3 all stores issued, 4 stores drained
- * and counted.  Row workgroups (kind 1): 0 task start, 1 all tiles stored, 2 rows in registers and
- * counted, 3 rows transformed (wave 0).  Synchronous; timing of this call is not representative. */
+ * ticks) copied to host_stamps[2 x CUs workgroups][16 tasks][9].  Slot 8 of task 0 identifies the
+ * workgroup: kind << 32 | xcc << 16 | rank; the meaning of slots 0-7 per kind is listed in
+ * tools/fused_stamps.py.  Synchronous; timing of this call is not representative. */
 int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                            unsigned long long *host_stamps, size_t host_count);
 

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Phase anatomy of the fused launch (wrp_debug_fused_stamps, a separate diagnostic instantiation).
-Every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 7 of task 0 holds
+Every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 8 of task 0 holds
 kind << 32 | xcc << 16 | rank.
-  tile workgroups: 0 task start, 1 stage 1 done (tile had arrived), 2 group 0 transformed + previous rows
-                   loaded, 3 all stores issued, 4 stores drained and counted
-  row workgroups : 0 task start, 1 all tiles stored, 2 rows in registers and counted, 3 rows transformed
+  tile workgroups: 0 task start, 1 stage 1 done (barrier A1), 2 group 0 transformed + half 0 free (A2),
+                   3 half 0 stored and drained, next tile requested, group 1 in LDS (A3), 4 group 1
+                   transformed + half 1 free (A4)
+  row workgroups : per half g: 4g + 0 start, + 1 half stored by all tiles, + 2 row in registers and counted,
+                   + 3 row transformed
 Read the SHARES, not the length: stamps forbid overlaps the real launch has."""
 import ctypes as C
 import os
@@ -28,7 +30,7 @@ def main():
     d_out = torch.empty((S, 512, 2), dtype=torch.float32, device=dev)
     eng = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1)
     nwg = torch.cuda.get_device_properties(0).multi_processor_count * 2
-    st = np.zeros((nwg, 16, 8), np.uint64)
+    st = np.zeros((nwg, 16, 9), np.uint64)
     lib = eng.lib
     for _ in range(2):
         rc = lib.wrp_debug_fused_stamps(eng.handle, C.c_void_p(d_iq.data_ptr()), S, C.c_void_p(d_out.data_ptr()),
@@ -36,16 +38,17 @@ def main():
         assert rc == 0, (rc, lib.wrp_last_hip_error(eng.handle))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "stamps.npy"), st)
-    ident = st[:, 0, 7]
+    ident = st[:, 0, 8]
     kind = (ident >> np.uint64(32)).astype(int)
     xcc = ((ident >> np.uint64(16)) & np.uint64(0xffff)).astype(int)
     print("workgroups per (kind, xcc):", {(k, x): int(((kind == k) & (xcc == x)).sum()) for k in (0, 1) for x in range(8)})
     t = st.astype(np.float64) / 100.0     # us
     tasks = min(16, 2 * (S // 8))
     r = slice(3, tasks)
-    names = {0: ["stage 1 (incl. wait for the tile)", "group 0 stages 2-3 + wait rows loaded", "store, group 1, prefetch, stores",
-                 "drain + barrier + count"],
-             1: ["wait tiles stored", "row loads + barrier + count", "two row transforms (wave 0)"]}
+    names = {0: ["stage 1 (incl. wait for the tile) .. A1", "group 0 stages 2-3 + wait half 0 free .. A2",
+                 "store, request, group 1 to LDS, drain .. A3", "group 1 stages 2-3 + wait half 1 free .. A4"],
+             1: ["half 0: wait stored", "half 0: row load + barrier + count", "half 0: row transform",
+                 "(between halves)", "half 1: wait stored", "half 1: row load + barrier + count", "half 1: row transform"]}
     for k, label in ((0, "tile"), (1, "row")):
         sel = kind == k
         d = np.diff(t[sel][:, r, :len(names[k]) + 1], axis=2)

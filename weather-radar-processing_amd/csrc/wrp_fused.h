@@ -20,10 +20,17 @@
 // other.  Team e owns sectors e, e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...
 //   tile member r : range tile r (columns 16 r ..) of every task  -> the team's ONE 2 MiB buffer
 //   row member r  : gates 16 r .. 16 r + 15 of every task (wave w: gates 16 r + 2 w, + 1), a4 .. a9
-// Hand-offs (one buffer, so both directions):
-//   stored : tile members count a task's tile once its stores have drained; row members wait for 32
-//   loaded : row members count once their 16 rows are in registers; tile members wait for 32 before
-//            they overwrite the buffer with the next task's tile
+// Hand-offs.  The buffer is handed over in two HALVES g = 0, 1 -- the gates with (gate mod 16) in
+// [8 g, 8 g + 8), which is exactly what k1-group g of a tile produces (see below) -- each with its own
+// pair of counters, so that a tile member never waits for the row members in steady state:
+//   stored[g] : tile members count a task's half once its stores have drained; row members wait for 32
+//   loaded[g] : row members count once their 8 rows of the half are in registers; tile members wait
+//               for 32 before they overwrite the half with the next task's
+// A tile member stores half 0 in the middle of a tile and half 1 at its end; the rows of half g are
+// loaded while the tile members transform the other half, a whole half-tile before they need the
+// space again.  Store drains are waited for where they cost nothing: half 0 behind the next tile's
+// requests (counted s_waitcnt: the loads are younger than the stores), half 1 behind the next
+// tile's stage 1.
 // Each counter exists in 32 replicas on lines of their own; a signalling workgroup adds to all 32
 // with ONE wave instruction and every waiter polls only ITS replica (32 workgroups polling one line
 // took 2.7 us to notice a count in round 1).  Counters are monotonic over tasks.  All of this stays
@@ -51,7 +58,7 @@ namespace wrp {
 constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_MEMBERS = 32;                  // tile members = row members per team = CUs per XCD
 constexpr int FUSED_STAMP_TASKS = 16;
-constexpr int FUSED_STAMPS = 8;
+constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (task 0)
 constexpr size_t FUSED_TEAM_ELEMS = (size_t)(RP_M / 2) * DP_N;   // float2 units: ONE mid[512][512] per team
 
 struct FusedLine { unsigned w; unsigned pad[31]; };   // one counter per 128-byte line
@@ -62,8 +69,8 @@ struct FusedCtl {               // zeroed by hipMemsetAsync before every launch
     unsigned census[2][8];      // workgroups per kind (0 tile, 1 row) and XCC
     unsigned pad1[16];
     unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
-    FusedLine stored[8][FUSED_MEMBERS];      // [xcc][replica r]: tiles stored so far; polled by row member r only
-    FusedLine loaded[8][FUSED_MEMBERS];      // [xcc][replica r]: row sets loaded so far; polled by tile member r only
+    FusedLine stored[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: tile halves stored so far; polled by row member r only
+    FusedLine loaded[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: row sets loaded so far; polled by tile member r only
 };
 static_assert(sizeof(FusedCtl) % 16 == 0, "memset block is a multiple of 16 bytes");
 
@@ -99,17 +106,29 @@ __device__ __forceinline__ unsigned hw_cu_key()   // se, sh, cu of the CU this w
 
 // Team counters are only ever touched by workgroups of ONE XCD, whose L2 performs every atomic:
 // additions are plain L2 atomics (workgroup scope, no sc1, the line stays in that L2).
-__device__ __forceinline__ void l2_count(unsigned *p)
+// One wave instruction, 32 lanes: lane r adds to replica r (line r of `lines`).  The lane offset is
+// recomputed at every call: kept across the task loop it is spilled, and the reload of a spilled
+// address waits (vmcnt, in order) for every request in flight -- the whole next tile.
+__device__ __forceinline__ void l2_count32(FusedLine *lines /* wave-uniform */, int l)
 {
-    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" : "+v"(l));
+    if (l < FUSED_MEMBERS) __hip_atomic_fetch_add(&lines[l].w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// POLL = 0: an atomic add of 0 with return (performed at the L2; the zero is hidden from the
-// compiler, which otherwise folds the idempotent atomic into an sc0 load that hits the stale L1);
-// POLL = 1: a device-scope load (sc1: misses the L1, served by the L2).
+// POLL = 0: a SCALAR load with glc (misses the scalar cache, served by the L2).  Scalar memory
+// operations have their own counter (lgkmcnt): a vector poll -- load or atomic -- returns in order
+// behind the polling wave's own tile requests, i.e. after the HBM latency of a whole tile;
+// POLL = 1: a device-scope vector load (sc1: misses the L1, served by the L2);
+// POLL = 2: an atomic add of 0 with return (performed at the L2; the zero is hidden from the
+// compiler, which otherwise folds the idempotent atomic into an sc0 load that hits the stale L1).
 template <int POLL>
-__device__ __forceinline__ unsigned l2_peek(unsigned *p)
+__device__ __forceinline__ unsigned l2_peek(unsigned *p /* wave-uniform */)
 {
     if (POLL == 0) {
+        unsigned v;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+        return v;
+    }
+    if (POLL == 2) {
         unsigned zero = 0;
         asm volatile("" : "+v"(zero));
         return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -136,8 +155,13 @@ __device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *
 }
 
 // ---- tile member: device functions -----------------------------------------------------------
-// this lane's 16 row loads (rows p0 + 64 r of one column pair) + its two Doppler-window values;
-// valid = false -> zero-record descriptor, the hardware drops the loads (see range_load)
+// HALF of this lane's 16 row loads (rows p0 + 64 r, r = 8 half .. 8 half + 7, of one column pair);
+// half 1 also fetches the lane's two Doppler-window values.  valid = false -> zero-record descriptor,
+// the hardware drops the loads (see range_load).  The tile is requested in two halves because at
+// the rate this launch aims for the HBM stream of a CU must never pause: 128 KiB asked for at once
+// stall the requesting waves in the ISSUE (a CU takes a bounded number of outstanding lines) for
+// most of the time the tile needs to arrive.
+template <int HALF>
 __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                 float4 (&v)[16], float2 &wdv, bool valid)
 {
@@ -148,12 +172,30 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
     const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = buf_load_f4<AUX_NT>(rs, voff, 64 * r * DP_N * 8);
-    wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
+    for (int r = 8 * HALF; r < 8 * HALF + 8; r++) v[r] = buf_load_f4<AUX_NT>(rs, voff, 64 * r * DP_N * 8);
+    if (HALF == 1) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
 // stage 1 (a2 + first radix of a3): window, radix 16 over rows p0 + 64 r, twiddle W_1024^{p0 k1};
-// k1 < 8 goes to the LDS image (group 0), k1 >= 8 stays in ga / gc (group 1)
+// k1 < 8 goes to the LDS image (group 0), k1 >= 8 stays in ga / gc (group 1).  The lane's two columns
+// are transformed ONE AFTER THE OTHER (and written as 8-byte halves of their 16-byte slots): both at
+// once need more registers than the 128 that four waves per SIMD leave (165 in range_pass_1024).
+__device__ __forceinline__ void fused_stage1_column(unsigned char *smem, cf (&a)[16], int p0, int slot, cf (&g)[8])
+{
+    typedef FusedTile T;
+    fft16<-1>(a);
+    *reinterpret_cast<float2 *>(smem + slot) = a[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) {
+        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
+        *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t);
+    }
+#pragma unroll
+    for (int k1 = 8; k1 < 16; k1++) {
+        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
+        g[k1 - 8] = cmul(a[k1], t);
+    }
+}
 __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&ga)[8], cf (&gc)[8])
 {
     typedef FusedTile T;
@@ -162,28 +204,25 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
-    cf a[16], c[16];
+    const int slot = T::addr(p0, cp);   // position k1*64 + p0 is 8 k1 blocks further on
+    {
+        cf a[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float wrow = s_wr[p0 + 64 * r];
-        const float w0 = wrow * wdv.x, w1 = wrow * wdv.y;
-        a[r] = make_float2(v[r].x * w0, v[r].y * w0);
-        c[r] = make_float2(v[r].z * w1, v[r].w * w1);
+        for (int r = 0; r < 16; r++) {
+            const float w0 = s_wr[p0 + 64 * r] * wdv.x;
+            a[r] = make_float2(v[r].x * w0, v[r].y * w0);
+        }
+        fused_stage1_column(smem, a, p0, slot, ga);
     }
-    fft16<-1>(a);
-    fft16<-1>(c);
-    *reinterpret_cast<float4 *>(smem + T::addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        cf c[16];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
-        const cf x = cmul(a[k1], t), y = cmul(c[k1], t);
-        *reinterpret_cast<float4 *>(smem + T::addr(k1 * 64 + p0, cp)) = make_float4(x.x, x.y, y.x, y.y);
-    }
-#pragma unroll
-    for (int k1 = 8; k1 < 16; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
-        ga[k1 - 8] = cmul(a[k1], t);
-        gc[k1 - 8] = cmul(c[k1], t);
+        for (int r = 0; r < 16; r++) {
+            const float w1 = s_wr[p0 + 64 * r] * wdv.y;
+            c[r] = make_float2(v[r].z * w1, v[r].w * w1);
+        }
+        fused_stage1_column(smem, c, p0, slot + 8, gc);
     }
 }
 
@@ -200,14 +239,16 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
         *reinterpret_cast<float4 *>(smem + T::addr(j * 64 + p0, cp)) = make_float4(ga[j].x, ga[j].y, gc[j].x, gc[j].y);
 }
 
-// stages 2 and 3 of the sub-transform this WAVE owns in the current group (image rows w*64 ..):
-// wave-private, no workgroup barrier in between.  ONE column per lane here (col = l & 15, two items
-// per lane and stage), which halves the registers of these stages -- the next tile's 64 registers
-// are in flight meanwhile -- and keeps every 8-byte LDS access conflict-free: a wave-instruction
-// covers 4 positions x 128 contiguous bytes.  Same arithmetic per element as range_stage12/3.
-// o[it][k3] = gate k1 + 16 k2 + 128 k3 (k2 = (l >> 4) + 4 it, k3 < 4) of column col; the chain
-// never reads the other half of the gates (rpv2.cu:502).
-__device__ __forceinline__ void fused_stage23(unsigned char *smem, cf (&o)[2][4])
+// stages 2 and 3 of the sub-transform this WAVE owns in the current group (image rows w*64 ..) and
+// the stores of its gates: wave-private, no workgroup barrier in between.  ONE column per lane here
+// (col = l & 15, two items per lane and stage, one after the other), which keeps these stages at
+// ~40 registers -- the next tile's 64 registers are in flight meanwhile -- and every 8-byte LDS
+// access conflict-free: a wave-instruction covers 4 positions x 128 contiguous bytes.  Same
+// arithmetic per element as range_stage12/3.  Item `it` of stage 3 yields the gates
+// k1 + 16 k2 + 128 k3 (k1 = w + 8 group, k2 = (l >> 4) + 4 it, k3 < 4) of column col; the chain never
+// reads the other half of the gates (rpv2.cu:502).  Stores are plain: the lines stay in the XCD's
+// L2, where the row members find them; 16 lanes x 8 bytes = one whole 128-byte line per gate.
+__device__ __forceinline__ void fused_stage23_store(unsigned char *smem, float2 *mid /* wave-uniform */, int col_base, int group)
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
@@ -227,8 +268,11 @@ __device__ __forceinline__ void fused_stage23(unsigned char *smem, cf (&o)[2][4]
             const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((16 * p1 * k2) & (RP_M - 1)));
             *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t);
         }
+        __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved they need twice the registers
     }
     wave_lds_fence();
+    const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
+    const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
 #pragma unroll
     for (int it = 0; it < 2; it++) {   // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
         const int k2 = (l >> 4) + 4 * it;
@@ -237,27 +281,13 @@ __device__ __forceinline__ void fused_stage23(unsigned char *smem, cf (&o)[2][4]
         for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
         fft8<-1>(a);
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
-    }
-}
-
-// the stores of one group: plain (the lines stay in the XCD's L2, where the row members find them);
-// 16 lanes x 8 bytes = one whole 128-byte line per gate
-__device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
-{
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int w = tid >> 6, l = tid & 63, col = l & 15;
-    const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
-    const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
-#pragma unroll
-    for (int it = 0; it < 2; it++)
-#pragma unroll
         for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
             v2f t;
-            t.x = o[it][k3].x; t.y = o[it][k3].y;
+            t.x = a[k3].x; t.y = a[k3].y;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (64 * it + 128 * k3) * DP_N * 8, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int TAPS, int POLL, bool STAMPS>
@@ -313,7 +343,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     if (rank >= FUSED_MEMBERS) return;   // surplus workgroups own nothing
     const int tasks = 2 * ((n_sectors - trank + teams - 1) / teams);   // channel-tasks of this team
     float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
-    unsigned *my_stored = &ctl->stored[xcc][rank].w, *my_loaded = &ctl->loaded[xcc][rank].w;
     auto stamp = [&](int q, int k) {
         if (STAMPS && stamps && tid == 0 && q < FUSED_STAMP_TASKS)
             stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * FUSED_STAMPS + k] = __builtin_amdgcn_s_memrealtime();
@@ -328,7 +357,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
         float4 v[16];
         float2 wdv;
-        fused_tile_load(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);     // HBM requests first ...
+        fused_tile_load<0>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);   // HBM requests first ...
+        fused_tile_load<1>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
         for (int e = tid; e < RP_M; e += FUSED_THREADS) {                 // ... tables while they fly
             *reinterpret_cast<float2 *>(smem + T::tw_addr(e)) = rc.tw[e];
             reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
@@ -337,62 +367,68 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             cf ga[8], gc[8];
-            cf o[2][4];
             stamp(q, 0);
             fused_stage1(smem, v, wdv, ga, gc);
-            __syncthreads();                    // A1: group 0 is in the image
-            stamp(q, 1);
-            fused_stage23(smem, o);
-            // the buffer still holds task q-1 until every row member has its rows in registers
-            if (tid == 0) s_ctl[8] = q == 0 || spin_ge<POLL>(my_loaded, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
-            __syncthreads();                    // A2: group 0 has left the image; verdict of the wait
+            // half 0 of the buffer holds task q-1 until every row member has those rows in registers:
+            // counted half a tile ago, so this is a look, not a wait
+            if (tid == 0) s_ctl[8] = q == 0 || spin_ge<POLL>(&ctl->loaded[0][xcc][rank].w, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
+            // half 1 of the previous tile was stored a whole stage ago: its drain costs nothing here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                    // A1: group 0 is in the image; previous half 1 drained by every wave
             if (!s_ctl[8]) return;
+            if (q > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
+            stamp(q, 1);
+            // v is free: request the first half of the next tile; it flies during the rest of this one
+            const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
+            fused_tile_load<0>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage23_store(smem, mid, col0, 0);
+            __syncthreads();                    // A2: group 0 has left the image
             stamp(q, 2);
-            fused_store(mid, col0, 0, o);
+            // second half of the next tile, BEHIND the stores, so that a counted wait can tell them apart
+            fused_tile_load<1>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
             fused_group1_to_lds(smem, ga, gc);
-            __syncthreads();                    // A3: group 1 is in the image
-            // v is free: request the next tile now, it flies during the rest of this one
-            fused_tile_load(tile_src(q + 1 < tasks ? q + 1 : 0), col0, rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage23(smem, o);
-            fused_store(mid, col0, 1, o);
+            if (tid == 0) s_ctl[9] = q == 0 || spin_ge<POLL>(&ctl->loaded[1][xcc][rank].w, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // all but the 9 requests just issued: the stores are in the L2
+            __syncthreads();                    // A3: group 1 is in the image; half 0 drained by every wave
+            if (!s_ctl[9]) return;
+            if (w == 0) l2_count32(ctl->stored[0][xcc], l);
             stamp(q, 3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores are in the L2
-            __syncthreads();                    // A4: tile stored; image free for the next stage 1
-            if (w == 0 && l < FUSED_MEMBERS) l2_count(&ctl->stored[xcc][l].w);
+            fused_stage23_store(smem, mid, col0, 1);
+            __syncthreads();                    // A4: image free for the next stage 1
             stamp(q, 4);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tasks > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
     } else {
         // =============================== row member ===============================
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         for (int e = tid; e < DP_N; e += FUSED_THREADS) s_twn[e] = tw_n[e];
         const DumpPtrs nodump{};
-        const int g0 = rank * 16 + 2 * w;
-        float s_hh0 = 0.f, s_hh1 = 0.f;     // HH row sums of this wave's gates, waiting for the VV task
+        float s_hh[2] = {0.f, 0.f};     // HH row sums of this wave's two gates, waiting for the VV task
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
-            stamp(q, 0);
-            if (tid == 0) s_ctl[8] = spin_ge<POLL>(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status);
-            __syncthreads();                    // every tile of task q is in the buffer (and s_twn is filled)
-            if (!s_ctl[8]) return;
-            stamp(q, 1);
-            cf x0[8], x1[8];
-            doppler_load_row<AUX_SC1>(mid + (size_t)g0 * n, l, x0);
-            doppler_load_row<AUX_SC1>(mid + (size_t)(g0 + 1) * n, l, x1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the buffer may be overwritten
-            __syncthreads();
-            if (w == 0 && l < FUSED_MEMBERS) l2_count(&ctl->loaded[xcc][l].w);
-            stamp(q, 2);
-            const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g0, false, nodump);
-            const float s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump);
-            stamp(q, 3);
-            if ((q & 1) == 0) {
-                s_hh0 = s0;
-                s_hh1 = s1;
-            } else if (l == 0) {
-                float *o2 = &out[((size_t)(trank + (q >> 1) * teams) * gates + g0) * 2];
-                reflectivity_store(o2, g0, s_hh0, s0, k_rr, k_cal);
-                reflectivity_store(o2 + 2, g0 + 1, s_hh1, s1, k_rr, k_cal);
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int gate = rank * 16 + 8 * g + w;
+                stamp(q, 4 * g);
+                if (tid == 0)
+                    s_ctl[8 + g] = spin_ge<POLL>(&ctl->stored[g][xcc][rank].w, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status);
+                __syncthreads();                    // every tile's half g of task q is in the buffer (and s_twn is filled)
+                if (!s_ctl[8 + g]) return;
+                stamp(q, 4 * g + 1);
+                cf x[8];
+                doppler_load_row<AUX_SC1>(mid + (size_t)gate * n, l, x);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row in registers: the half may be overwritten
+                __syncthreads();
+                if (w == 0) l2_count32(ctl->loaded[g][xcc], l);
+                stamp(q, 4 * g + 2);
+                const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
+                stamp(q, 4 * g + 3);
+                if ((q & 1) == 0) s_hh[g] = s;
+                else if (l == 0)
+                    reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh[g], s, k_rr, k_cal);
             }
         }
     }
