@@ -2,11 +2,11 @@
 """Phase anatomy of the fused launch (wrp_debug_fused_stamps, a separate diagnostic instantiation).
 Every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 8 of task 0 holds
 kind << 32 | xcc << 16 | rank.
-  tile workgroups: 0 task start, 1 stage 1 done (barrier A1), 2 group 0 transformed + half 0 free (A2),
+  tile workgroups: 0 task start, 1 stage 1 done (barrier A1), 2 group 0 transformed (A2), next half requested, group 1 written,
                    3 half 0 stored and drained, next tile requested, group 1 in LDS (A3), 4 group 1
                    transformed + half 1 free (A4)
-  row workgroups : per half g: 4g + 0 start, + 1 half stored by all tiles, + 2 row in registers and counted,
-                   + 3 row transformed
+  row workgroups : wave 0 (half 0) slots 0-3, wave 4 (half 1) slots 4-7: + 0 task start, + 1 half stored by
+                   all tiles, + 2 rows in registers and counted, + 3 rows transformed
 Read the SHARES, not the length: stamps forbid overlaps the real launch has."""
 import ctypes as C
 import os
@@ -45,17 +45,32 @@ def main():
     t = st.astype(np.float64) / 100.0     # us
     tasks = min(16, 2 * (S // 8))
     r = slice(3, tasks)
-    names = {0: ["stage 1 (incl. wait for the tile) .. A1", "group 0 stages 2-3 + wait half 0 free .. A2",
-                 "store, request, group 1 to LDS, drain .. A3", "group 1 stages 2-3 + wait half 1 free .. A4"],
-             1: ["half 0: wait stored", "half 0: row load + barrier + count", "half 0: row transform",
-                 "(between halves)", "half 1: wait stored", "half 1: row load + barrier + count", "half 1: row transform"]}
+    names = {0: ["stage 1 (incl. wait for the tile) .. A1", "group 0 stages 2-3, A2, request, group 1 to LDS",
+                 "look at half 1 free, drain half 0 .. A3", "group 1 stages 2-3 .. A4"],
+             1: ["half 0: wait stored", "half 0: row loads + count", "half 0: two row transforms",
+                 "(wave 0 -> wave 4)", "half 1: wait stored", "half 1: row loads + count", "half 1: two row transforms"]}
     for k, label in ((0, "tile"), (1, "row")):
         sel = kind == k
         d = np.diff(t[sel][:, r, :len(names[k]) + 1], axis=2)
+        if k == 0:
+            x = t[sel][:, r, :]
+            print(f"    (inside 'look .. A3': look {np.median(x[:, :, 5] - x[:, :, 2]):.2f}, drain {np.median(x[:, :, 6] - x[:, :, 5]):.2f}, "
+                  f"barrier {np.median(x[:, :, 3] - x[:, :, 6]):.2f})")
         print(f"{label} workgroups ({int(sel.sum())}), tasks 3..{tasks - 1}; median (p10 .. p90) us")
         for i, nm in enumerate(names[k]):
             x = d[:, :, i].ravel()
             print(f"    {nm:42s} {np.median(x):7.2f}  ({np.percentile(x, 10):6.2f} .. {np.percentile(x, 90):6.2f})")
+        if k == 1:   # when, relative to the tile workgroups' A1 / A3 of the same task, do the rows get loaded
+            tt = t[kind == 0][:, r, :]
+            tr = t[sel][:, r, :]
+            for x in range(8):
+                a1 = np.median(tt[xcc[kind == 0] == x][:, :, 1], axis=0)
+                a3 = np.median(tt[xcc[kind == 0] == x][:, :, 3], axis=0)
+                h0 = np.median(tr[xcc[sel] == x][:, :, 2], axis=0)
+                h1 = np.median(tr[xcc[sel] == x][:, :, 6], axis=0)
+                if x == 0:
+                    print(f"    xcc 0: half 0 loaded - A3 of its task: {np.round(h0 - a3, 2)}")
+                    print(f"    xcc 0: half 1 loaded - A1 of the NEXT task: {np.round(h1[:-1] - a1[1:], 2)}")
         per = np.diff(t[sel][:, r, 0], axis=1).ravel()
         print(f"    task period: median {np.median(per):.2f} us (p10 {np.percentile(per, 10):.2f}, p90 {np.percentile(per, 90):.2f})"
               f"  -> {np.median(per) * 2 / 8:.2f} us/sector with 8 teams")

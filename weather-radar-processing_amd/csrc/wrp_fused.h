@@ -47,7 +47,7 @@
 // entirely in wave k1 mod 8 for stages 2 and 3.  So the tile goes through LDS in two GROUPS of
 // eight k1 (72 KiB instead of 144 KiB -- which is what lets two workgroups share a CU with
 // 16-column tiles, i.e. whole 128-byte lines); group 1 waits in 32 registers meanwhile, and only
-// the hand-over from stage 1 needs workgroup barriers (4 per tile).
+// the hand-over from stage 1 needs workgroup barriers (5 per tile, one of them for a count).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -82,7 +82,8 @@ struct FusedTile {
     static constexpr int IMG_BYTES = BLOCKS * BLK_BYTES;         // 73728
     static constexpr int OFF_WR = IMG_BYTES;                     // float wr_c[1024]
     static constexpr int OFF_CTL = OFF_WR + RP_M * 4;            // 77824: control words, both kinds
-    static constexpr int LDS_BYTES = OFF_CTL + 64;               // 77888 -> exactly two workgroups per CU
+    static constexpr int OFF_STAMPS = OFF_CTL + 64;              // diagnostics build: [16 tasks][9] 64-bit stamps
+    static constexpr int LDS_BYTES = OFF_STAMPS + FUSED_STAMP_TASKS * FUSED_STAMPS * 8;   // 79040 -> exactly two workgroups per CU
     // row workgroup: 8 wave buffers, then the Doppler twiddles
     static constexpr int OFF_TWN = 8 * DP_ELEMS * 8;             // 36864
     static_assert(OFF_TWN + DP_N * 8 <= OFF_CTL, "row workgroup layout fits");
@@ -155,13 +156,14 @@ __device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *
 }
 
 // ---- tile member: device functions -----------------------------------------------------------
-// HALF of this lane's 16 row loads (rows p0 + 64 r, r = 8 half .. 8 half + 7, of one column pair);
-// half 1 also fetches the lane's two Doppler-window values.  valid = false -> zero-record descriptor,
-// the hardware drops the loads (see range_load).  The tile is requested in two halves because at
-// the rate this launch aims for the HBM stream of a CU must never pause: 128 KiB asked for at once
-// stall the requesting waves in the ISSUE (a CU takes a bounded number of outstanding lines) for
-// most of the time the tile needs to arrive.
-template <int HALF>
+// A QUARTER of this lane's 16 row loads: rows p0 + 64 r with r = QUARTER mod 4 (r = QUARTER, + 4, + 8,
+// + 12: exactly the inputs of ONE first-level butterfly of the radix-16 stage, so stage 1 can start
+// on the quarters that have arrived); quarter 3 also fetches the lane's two Doppler-window values.
+// valid = false -> zero-record descriptor, the hardware drops the loads (see range_load).
+// The tile is requested in quarters because a CU takes a bounded number of outstanding requests: a
+// whole tile (128 KiB) asked for at once stalls the requesting waves in the ISSUE for most of the
+// time the tile needs to arrive, and every L2 hit of the CU's row workgroup queues behind it.
+template <int QUARTER>
 __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                 float4 (&v)[16], float2 &wdv, bool valid)
 {
@@ -172,8 +174,8 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
     const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
 #pragma unroll
-    for (int r = 8 * HALF; r < 8 * HALF + 8; r++) v[r] = buf_load_f4<AUX_NT>(rs, voff, 64 * r * DP_N * 8);
-    if (HALF == 1) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
+    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<AUX_NT>(rs, voff, 64 * r * DP_N * 8);
+    if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
 // stage 1 (a2 + first radix of a3): window, radix 16 over rows p0 + 64 r, twiddle W_1024^{p0 k1};
@@ -196,7 +198,8 @@ __device__ __forceinline__ void fused_stage1_column(unsigned char *smem, cf (&a)
         g[k1 - 8] = cmul(a[k1], t);
     }
 }
-__device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&ga)[8], cf (&gc)[8])
+template <int COLUMN>   // 0: the lane's first column (v[r].xy), 1: its second (v[r].zw)
+__device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&g)[8])
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
@@ -204,26 +207,14 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
-    const int slot = T::addr(p0, cp);   // position k1*64 + p0 is 8 k1 blocks further on
-    {
-        cf a[16];
+    const int slot = T::addr(p0, cp) + 8 * COLUMN;   // position k1*64 + p0 is 8 k1 blocks further on
+    cf a[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float w0 = s_wr[p0 + 64 * r] * wdv.x;
-            a[r] = make_float2(v[r].x * w0, v[r].y * w0);
-        }
-        fused_stage1_column(smem, a, p0, slot, ga);
+    for (int r = 0; r < 16; r++) {
+        const float wgt = s_wr[p0 + 64 * r] * (COLUMN ? wdv.y : wdv.x);
+        a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        cf c[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float w1 = s_wr[p0 + 64 * r] * wdv.y;
-            c[r] = make_float2(v[r].z * w1, v[r].w * w1);
-        }
-        fused_stage1_column(smem, c, p0, slot + 8, gc);
-    }
+    fused_stage1_column(smem, a, p0, slot, g);
 }
 
 // group 1 from its registers into the image (after group 0 has left it)
@@ -248,7 +239,7 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
 // k1 + 16 k2 + 128 k3 (k1 = w + 8 group, k2 = (l >> 4) + 4 it, k3 < 4) of column col; the chain never
 // reads the other half of the gates (rpv2.cu:502).  Stores are plain: the lines stay in the XCD's
 // L2, where the row members find them; 16 lanes x 8 bytes = one whole 128-byte line per gate.
-__device__ __forceinline__ void fused_stage23_store(unsigned char *smem, float2 *mid /* wave-uniform */, int col_base, int group)
+__device__ __forceinline__ void fused_stage2(unsigned char *smem)
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
@@ -271,6 +262,14 @@ __device__ __forceinline__ void fused_stage23_store(unsigned char *smem, float2 
         __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved they need twice the registers
     }
     wave_lds_fence();
+}
+__device__ __forceinline__ void fused_stage3_store(unsigned char *smem, float2 *mid /* wave-uniform */, int col_base, int group)
+{
+    typedef FusedTile T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
     const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
     const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
 #pragma unroll
@@ -343,13 +342,27 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     if (rank >= FUSED_MEMBERS) return;   // surplus workgroups own nothing
     const int tasks = 2 * ((n_sectors - trank + teams - 1) / teams);   // channel-tasks of this team
     float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
-    auto stamp = [&](int q, int k) {
-        if (STAMPS && stamps && tid == 0 && q < FUSED_STAMP_TASKS)
-            stamps[((size_t)blockIdx.x * FUSED_STAMP_TASKS + q) * FUSED_STAMPS + k] = __builtin_amdgcn_s_memrealtime();
+    // diagnostics build only: stamps go to LDS (no vector-memory traffic in the timed phases) and
+    // are copied out at the end by wave 0
+    unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(smem + T::OFF_STAMPS);
+    auto stamp = [&](int q, int k) {   // wave 0 -> slots k; row kind: also wave 4 (half 1) -> slots 4 + k
+        if (STAMPS && (w == 0 || (kind == 1 && w == 4)) && q < FUSED_STAMP_TASKS) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if (l == 0) s_stamps[q * FUSED_STAMPS + k + w] = t;
+        }
     };
-    if (STAMPS && stamps && tid == 0)   // kind, xcc, rank in the last slot of task 0
-        stamps[(size_t)blockIdx.x * FUSED_STAMP_TASKS * FUSED_STAMPS + FUSED_STAMPS - 1] =
-            ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
+    if (STAMPS) {
+        for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS) s_stamps[e] = 0;
+        __syncthreads();
+        if (tid == 0) s_stamps[FUSED_STAMPS - 1] = ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
+    }
+    auto flush_stamps = [&]() {
+        if (STAMPS && stamps) {
+            __syncthreads();
+            for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS)
+                stamps[(size_t)blockIdx.x * FUSED_STAMP_TASKS * FUSED_STAMPS + e] = s_stamps[e];
+        }
+    };
 
     if (kind == 0) {
         // =============================== tile member ===============================
@@ -359,6 +372,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         float2 wdv;
         fused_tile_load<0>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);   // HBM requests first ...
         fused_tile_load<1>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
+        fused_tile_load<2>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
+        fused_tile_load<3>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
         for (int e = tid; e < RP_M; e += FUSED_THREADS) {                 // ... tables while they fly
             *reinterpret_cast<float2 *>(smem + T::tw_addr(e)) = rc.tw[e];
             reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
@@ -368,69 +383,92 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         for (int q = 0; q < tasks; q++) {
             cf ga[8], gc[8];
             stamp(q, 0);
-            fused_stage1(smem, v, wdv, ga, gc);
+            fused_stage1<0>(smem, v, wdv, ga);
+            // Half 1 of the previous tile was stored half a stage ago: its drain costs nothing here.  It is
+            // counted NOW, while this CU has no request in flight: the row members load that half at once,
+            // and L2 hits of a CU queue (3.5 us measured) behind a request burst that went out before them.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                    // A0: previous half 1 drained by every wave
+            if (q > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
+            fused_stage1<1>(smem, v, wdv, gc);
             // half 0 of the buffer holds task q-1 until every row member has those rows in registers:
             // counted half a tile ago, so this is a look, not a wait
             if (tid == 0) s_ctl[8] = q == 0 || spin_ge<POLL>(&ctl->loaded[0][xcc][rank].w, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
-            // half 1 of the previous tile was stored a whole stage ago: its drain costs nothing here
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                    // A1: group 0 is in the image; previous half 1 drained by every wave
+            __syncthreads();                    // A1: group 0 is in the image
             if (!s_ctl[8]) return;
-            if (q > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
             stamp(q, 1);
-            // v is free: request the first half of the next tile; it flies during the rest of this one
+            // v is free: the next tile is requested a quarter at a time over the rest of this one
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
             fused_tile_load<0>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage23_store(smem, mid, col0, 0);
-            __syncthreads();                    // A2: group 0 has left the image
-            stamp(q, 2);
-            // second half of the next tile, BEHIND the stores, so that a counted wait can tell them apart
+            fused_stage2(smem);
             fused_tile_load<1>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage3_store(smem, mid, col0, 0);
+            __syncthreads();                    // A2: group 0 has left the image
+            // BEHIND the stores, so that a counted wait can tell them apart
+            fused_tile_load<2>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
             fused_group1_to_lds(smem, ga, gc);
+            stamp(q, 2);   // (placed right behind A2 this stamp makes hipcc spill 46 registers)
             if (tid == 0) s_ctl[9] = q == 0 || spin_ge<POLL>(&ctl->loaded[1][xcc][rank].w, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
-            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // all but the 9 requests just issued: the stores are in the L2
+            stamp(q, 5);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
+            stamp(q, 6);
             __syncthreads();                    // A3: group 1 is in the image; half 0 drained by every wave
             if (!s_ctl[9]) return;
             if (w == 0) l2_count32(ctl->stored[0][xcc], l);
             stamp(q, 3);
-            fused_stage23_store(smem, mid, col0, 1);
+            fused_tile_load<3>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage2(smem);
+            fused_stage3_store(smem, mid, col0, 1);
             __syncthreads();                    // A4: image free for the next stage 1
             stamp(q, 4);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tasks > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
+        flush_stamps();
     } else {
         // =============================== row member ===============================
+        // Eight independent waves, no workgroup barrier in the loop: waves 0-3 own the member's 8 gates
+        // of half 0 (two each), waves 4-7 those of half 1, so a wave has a whole task period for its
+        // two rows and the halves do not wait for each other.  A wave polls the member's replica
+        // itself (scalar loads); the last of a half's four waves to have its rows in registers
+        // (counted in LDS) counts the member as loaded.
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         for (int e = tid; e < DP_N; e += FUSED_THREADS) s_twn[e] = tw_n[e];
+        if (tid < 2) s_ctl[12 + tid] = 0;
+        __syncthreads();
         const DumpPtrs nodump{};
-        float s_hh[2] = {0.f, 0.f};     // HH row sums of this wave's two gates, waiting for the VV task
+        const int g = w >> 2;                                  // this wave's half
+        const int g0 = rank * 16 + 8 * g + 2 * (w & 3);        // its gates g0, g0 + 1
+        unsigned *my_stored = &ctl->stored[g][xcc][rank].w;
+        float s_hh0 = 0.f, s_hh1 = 0.f;     // HH row sums of this wave's gates, waiting for the VV task
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                const int gate = rank * 16 + 8 * g + w;
-                stamp(q, 4 * g);
-                if (tid == 0)
-                    s_ctl[8 + g] = spin_ge<POLL>(&ctl->stored[g][xcc][rank].w, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status);
-                __syncthreads();                    // every tile's half g of task q is in the buffer (and s_twn is filled)
-                if (!s_ctl[8 + g]) return;
-                stamp(q, 4 * g + 1);
-                cf x[8];
-                doppler_load_row<AUX_SC1>(mid + (size_t)gate * n, l, x);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row in registers: the half may be overwritten
-                __syncthreads();
-                if (w == 0) l2_count32(ctl->loaded[g][xcc], l);
-                stamp(q, 4 * g + 2);
-                const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
-                stamp(q, 4 * g + 3);
-                if ((q & 1) == 0) s_hh[g] = s;
-                else if (l == 0)
-                    reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh[g], s, k_rr, k_cal);
+            stamp(q, 0);
+            if (!spin_ge<POLL>(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) return;
+            stamp(q, 1);
+            cf x0[8], x1[8];
+            doppler_load_row<AUX_SC1>(mid + (size_t)g0 * n, l, x0);
+            doppler_load_row<AUX_SC1>(mid + (size_t)(g0 + 1) * n, l, x1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the half may be overwritten
+            int last = 0;
+            if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
+            if (__builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->loaded[g][xcc], l);
+            stamp(q, 2);
+            const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g0, false, nodump);
+            const float s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump);
+            stamp(q, 3);
+            if ((q & 1) == 0) {
+                s_hh0 = s0;
+                s_hh1 = s1;
+            } else if (l == 0) {
+                float *o2 = &out[((size_t)(trank + (q >> 1) * teams) * gates + g0) * 2];
+                reflectivity_store(o2, g0, s_hh0, s0, k_rr, k_cal);
+                reflectivity_store(o2 + 2, g0 + 1, s_hh1, s1, k_rr, k_cal);
             }
         }
+        flush_stamps();
     }
 }
 
