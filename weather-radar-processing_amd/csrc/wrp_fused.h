@@ -155,6 +155,41 @@ __device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *
     return false;
 }
 
+// the same wait for a wave in the middle of a tile: no early return (an exit edge there costs the
+// tile loop 14 spilled registers); a wave that gave up remembers it (`failed`, wave-uniform), stops
+// waiting and runs on -- the launch is reported as failed through `status` and its output discarded
+template <int POLL>
+__device__ __forceinline__ void spin_ge_sticky(unsigned *p, unsigned target, unsigned *status, int &failed)
+{
+    if (POLL == 0) {
+        // the whole bounded loop is ONE asm statement: hipcc sees no control flow, so the registers
+        // that are live across it (a tile's worth) are not split around a loop and spilled
+        unsigned v, budget = failed ? 1u : (1u << 22);
+        asm volatile("wrp_spin%=:\n\t"
+                     "s_load_dword %0, %2, 0x0 glc\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_cmp_ge_u32 %0, %3\n\t"
+                     "s_cbranch_scc1 wrp_done%=\n\t"
+                     "s_sub_u32 %1, %1, 1\n\t"
+                     "s_cmp_eq_u32 %1, 0\n\t"
+                     "s_cbranch_scc1 wrp_done%=\n\t"
+                     "s_sleep 1\n\t"
+                     "s_branch wrp_spin%=\n"
+                     "wrp_done%=:"
+                     : "=&s"(v), "+s"(budget) : "s"(p), "s"(target) : "memory", "scc");
+        failed |= budget == 0;   // straight-line code here; the caller reports `failed` once, after its loop
+        return;
+    }
+    if (failed) return;
+#pragma unroll 1
+    for (unsigned spins = 0; spins < (1u << 22); spins++) {
+        if (l2_peek<POLL>(p) >= target) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    failed = 1;
+    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- tile member: device functions -----------------------------------------------------------
 // A QUARTER of this lane's 16 row loads: rows p0 + 64 r with r = QUARTER mod 4 (r = QUARTER, + 4, + 8,
 // + 12: exactly the inputs of ONE first-level butterfly of the radix-16 stage, so stage 1 can start
@@ -366,65 +401,85 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
 
     if (kind == 0) {
         // =============================== tile member ===============================
-        const int col0 = rank * 16;
+        // Tile of task q: (rank + q) mod 32.  The column tiles 3, 11, 19, 27 -- byte offset 384 mod 1024 of
+        // every 4 KiB row -- load 18 % slower than the others on this chip (tools/storeskew.hip; an
+        // address-interleave artefact of the 4 KiB row stride), and a team moves at the pace of its slowest
+        // member: rotating the tiles makes that a transient of each member, which the slack of the
+        // hand-overs absorbs, instead of four members that are always late.
+        auto tile_col = [&](int q) { return ((rank + q) & (FUSED_MEMBERS - 1)) * 16; };
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
         float4 v[16];
         float2 wdv;
-        fused_tile_load<0>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);   // HBM requests first ...
-        fused_tile_load<1>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
-        fused_tile_load<2>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
-        fused_tile_load<3>(tile_src(0), col0, rc.wd, v, wdv, tasks > 0);
+        fused_tile_load<0>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);   // HBM requests first ...
+        fused_tile_load<1>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_tile_load<2>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_tile_load<3>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
         for (int e = tid; e < RP_M; e += FUSED_THREADS) {                 // ... tables while they fly
             *reinterpret_cast<float2 *>(smem + T::tw_addr(e)) = rc.tw[e];
             reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
         }
         __syncthreads();
+        // The tile waves are the critical path of a task and the row waves of this CU have slack: when
+        // both want the SIMD, the tile wave goes first.
+        // (s_setprio for the tile waves was measured: see DESIGN.md)
+        int *s_arrived = reinterpret_cast<int *>(smem + T::OFF_CTL + 56);   // two arrival counters (the row kind uses +48, +52)
+        if (tid < 2) s_arrived[tid] = 0;
+        __syncthreads();
+        unsigned *my_loaded0 = &ctl->loaded[0][xcc][rank].w, *my_loaded1 = &ctl->loaded[1][xcc][rank].w;
+        int failed = 0;
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             cf ga[8], gc[8];
             stamp(q, 0);
             fused_stage1<0>(smem, v, wdv, ga);
             // Half 1 of the previous tile was stored half a stage ago: its drain costs nothing here.  It is
-            // counted NOW, while this CU has no request in flight: the row members load that half at once,
-            // and L2 hits of a CU queue (3.5 us measured) behind a request burst that went out before them.
+            // counted NOW, while this CU has no request in flight (the row members load that half at once,
+            // and L2 hits of a CU queue -- 3.5 us measured -- behind a request burst that went out before
+            // them), by the last wave to get here: an arrival count in LDS instead of a barrier.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                    // A0: previous half 1 drained by every wave
-            if (q > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
+            int last = 0;
+            if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
+            if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->stored[1][xcc], l);
             fused_stage1<1>(smem, v, wdv, gc);
-            // half 0 of the buffer holds task q-1 until every row member has those rows in registers:
-            // counted half a tile ago, so this is a look, not a wait
-            if (tid == 0) s_ctl[8] = q == 0 || spin_ge<POLL>(&ctl->loaded[0][xcc][rank].w, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
             __syncthreads();                    // A1: group 0 is in the image
-            if (!s_ctl[8]) return;
             stamp(q, 1);
             // v is free: the next tile is requested a quarter at a time over the rest of this one
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
-            fused_tile_load<0>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_tile_load<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
-            fused_tile_load<1>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage3_store(smem, mid, col0, 0);
+            fused_tile_load<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+            // Half 0 of the buffer holds task q-1 until every row member has those rows in registers.  The
+            // hand-over cycle of a half -- stored, seen by the rows, loaded, seen here: about 4 us -- plus the
+            // way from this look to the next count bounds the task period from below, so every wave looks
+            // for itself and as late as it can: right in front of its first store.
+            spin_ge_sticky<POLL>(my_loaded0, (unsigned)(FUSED_MEMBERS * q), &ctl->status, failed);
+            stamp(q, 5);
+            fused_stage3_store(smem, mid, tile_col(q), 0);
             __syncthreads();                    // A2: group 0 has left the image
             // BEHIND the stores, so that a counted wait can tell them apart
-            fused_tile_load<2>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_group1_to_lds(smem, ga, gc);
             stamp(q, 2);   // (placed right behind A2 this stamp makes hipcc spill 46 registers)
-            if (tid == 0) s_ctl[9] = q == 0 || spin_ge<POLL>(&ctl->loaded[1][xcc][rank].w, (unsigned)(FUSED_MEMBERS * q), &ctl->status);
-            stamp(q, 5);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
+            // ... and counted by the last wave to get here, without waiting for the barrier
+            last = 0;
+            if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
+            if (__builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->stored[0][xcc], l);
             stamp(q, 6);
-            __syncthreads();                    // A3: group 1 is in the image; half 0 drained by every wave
-            if (!s_ctl[9]) return;
-            if (w == 0) l2_count32(ctl->stored[0][xcc], l);
+            __syncthreads();                    // A3: group 1 is in the image
             stamp(q, 3);
-            fused_tile_load<3>(next, col0, rc.wd, v, wdv, q + 1 < tasks);
+            fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
-            fused_stage3_store(smem, mid, col0, 1);
+            spin_ge_sticky<POLL>(my_loaded1, (unsigned)(FUSED_MEMBERS * q), &ctl->status, failed);
+            stamp(q, 7);
+            fused_stage3_store(smem, mid, tile_col(q), 1);
             __syncthreads();                    // A4: image free for the next stage 1
             stamp(q, 4);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tasks > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
+        if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flush_stamps();
     } else {
         // =============================== row member ===============================
