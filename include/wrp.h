@@ -80,10 +80,6 @@ typedef struct {
  * next tile while the current one is being transformed.  This flag selects the
  * one-tile-per-workgroup form instead (same arithmetic, bit-identical results; A/B only). */
 #define WRP_FLAG_ONE_TILE_PER_BLOCK 0x400
-/* tuning (A/B): the fused launch polls its team counters with scalar loads by default; these select
- * device-scope vector loads or L2 atomics instead */
-#define WRP_FLAG_FUSED_POLL_LOAD 0x1000
-#define WRP_FLAG_FUSED_POLL_ATOMIC 0x2000
 
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
 typedef enum {

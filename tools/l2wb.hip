@@ -21,7 +21,7 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 __device__ unsigned g_rank[8];
 template <int MODE>   // 0: stores only; 1: + sc1 read-back; 2: + nt input stream; 3: both; +4: the chunks of one XCD are contiguous
-__global__ __launch_bounds__(512) void k_rewrite(float *buf, const float *in, float *sink, int chunk, int reps, int stream, int aux_sel)
+__global__ __launch_bounds__(512) void k_rewrite(float *buf, const float *in, float *sink, int chunk, int reps, int stream, int aux_sel, int st_sel)
 {
     const int tid = threadIdx.x;
     __shared__ unsigned s_slot;
@@ -38,7 +38,10 @@ __global__ __launch_bounds__(512) void k_rewrite(float *buf, const float *in, fl
     for (int r = 0; r < reps; r++) {
         for (int off = tid * 16; off < chunk; off += 512 * 16) {
             v4f v = {(float)r, (float)off, 1.f, 2.f};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 0);
+            // cache policy of the rewritten buffer's stores: 0 plain, 1 nt, 2 sc0
+            if (st_sel == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 0);
+            else if (st_sel == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -74,6 +77,7 @@ int main(int argc, char **argv)
     const int chunk = argc > 3 ? atoi(argv[3]) : 65536;      // 64 KiB x 32 CUs = 2 MiB per XCD
     const int stream = argc > 4 ? atoi(argv[4]) : 131072;    // 128 KiB per workgroup and repetition
     const int aux_sel = argc > 5 ? atoi(argv[5]) : 1;
+    const int st_sel = argc > 6 ? atoi(argv[6]) : 0;
     float *buf, *in, *sink;
     CK(hipMalloc(&buf, (size_t)256 * chunk));
     CK(hipMalloc(&in, (size_t)256 * stream * reps + 4096));
@@ -81,13 +85,13 @@ int main(int argc, char **argv)
     CK(hipMemset(in, 1, (size_t)256 * stream * reps));
     CK(hipDeviceSynchronize());
     switch (mode) {
-    case 0: hipLaunchKernelGGL(k_rewrite<0>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
-    case 1: hipLaunchKernelGGL(k_rewrite<1>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
-    case 2: hipLaunchKernelGGL(k_rewrite<2>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
-    case 3: hipLaunchKernelGGL(k_rewrite<3>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
-    case 4: hipLaunchKernelGGL(k_rewrite<4>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
-    case 5: hipLaunchKernelGGL(k_rewrite<5>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
-    default: hipLaunchKernelGGL(k_rewrite<7>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel); break;
+    case 0: hipLaunchKernelGGL(k_rewrite<0>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
+    case 1: hipLaunchKernelGGL(k_rewrite<1>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
+    case 2: hipLaunchKernelGGL(k_rewrite<2>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
+    case 3: hipLaunchKernelGGL(k_rewrite<3>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
+    case 4: hipLaunchKernelGGL(k_rewrite<4>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
+    case 5: hipLaunchKernelGGL(k_rewrite<5>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
+    default: hipLaunchKernelGGL(k_rewrite<7>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
     }
     CK(hipDeviceSynchronize());
     printf("mode %d reps %d chunk %d stream %d: stored per generation %.1f MiB, streamed per repetition %.1f MiB\n", mode, reps,

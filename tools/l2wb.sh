@@ -15,7 +15,10 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
 print(f"{sys.argv[2]:28s} {sys.argv[3]} = {tot / 1024:.1f} MiB")
 PY
 }
-for aux in 0 1 2 3 4 5; do
-  run w_m7_c65536_aux$aux WRITE_SIZE 7 50 65536 131072 $aux
-  run w_m7_c49152_aux$aux WRITE_SIZE 7 50 49152 131072 $aux
+for st in 0 1 2; do
+  run w_m7_c65536_st$st WRITE_SIZE 7 50 65536 131072 1 $st
+  run f_m7_c65536_st$st FETCH_SIZE 7 50 65536 131072 1 $st
 done
+# half the stream per repetition (what a longer-lived buffer would see per generation)
+run w_m7_c65536_s64k WRITE_SIZE 7 50 65536 65536 1 0
+run w_m7_c65536_s32k WRITE_SIZE 7 50 65536 32768 1 0

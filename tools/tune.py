@@ -3,8 +3,7 @@
 
   python tools/tune.py --variants "tcols=16,mb=24;tcols=8,mb=24" --sectors 360 --rounds 5
 
-Each variant is a comma list of key=value: fused (1 default | 0 = two kernels), pollload (fused: poll
-counters with loads), tcols (two-kernel range-pass tile, 8|16), onetile, mb (max_batch).
+Each variant is a comma list of key=value: fused (1 default | 0 = two kernels), tcols (two-kernel range-pass tile, 8|16), onetile, mb (max_batch).
 Reports median / min us per sector for total, range pass and Doppler pass.
 """
 import argparse
@@ -18,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="fused=1;fused=1,pollload=1;fused=1,pollatomic=1;fused=0")
+    ap.add_argument("--variants", default="fused=1;fused=0")
     ap.add_argument("--sectors", type=int, default=360)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=5)
@@ -42,7 +41,7 @@ def main():
         kv = dict(x.split("=") for x in spec.split(","))
         cfg = dict(n_slots=1, n_sectors=1, n_elevations=1)
         cfg["flags"] = (int(kv.get("tcols", 0)) | (0 if int(kv.get("fused", 1)) else 0x800) |
-                        (0x400 if int(kv.get("onetile", 0)) else 0) | (0x1000 if int(kv.get("pollload", 0)) else 0) | (0x2000 if int(kv.get("pollatomic", 0)) else 0))
+                        (0x400 if int(kv.get("onetile", 0)) else 0))
         if "mb" in kv:
             cfg["max_batch"] = int(kv["mb"])
         e = wrp_amd.Engine(device=0, **cfg)

@@ -11,8 +11,6 @@ needs libwrp.so and a GPU and raises :class:`WrpError` otherwise.
 from .binding import (  # noqa: F401
     Engine,
     FLAG_FUSED,
-    FLAG_FUSED_POLL_LOAD,
-    FLAG_FUSED_POLL_ATOMIC,
     FLAG_ONE_TILE_PER_BLOCK,
     FLAG_TWO_KERNELS,
     FUSED_MIN_SECTORS,

@@ -52,7 +52,6 @@ struct wrp_engine {
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors
     bool fused = false;
-    int fused_poll = 0;             // how team counters are polled: 0 scalar loads, 1 sc1 vector loads, 2 L2 atomics (tuning)
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_mid_pool = nullptr;   // per XCD team: ONE mid[m/2][n]
@@ -219,18 +218,14 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
-#define WRP_FUSED(TAPS, POLL, STAMPS)                                                                                 \
-    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, POLL, STAMPS>), dim3(h->n_cus * 2), dim3(wrp::FUSED_THREADS), \
+#define WRP_FUSED(TAPS, STAMPS)                                                                                       \
+    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(h->n_cus * 2), dim3(wrp::FUSED_THREADS),       \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
     if (d_stamps) {
-        if (h->taps_pad == 7) WRP_FUSED(7, 0, true); else WRP_FUSED(9, 0, true);
-    } else if (h->fused_poll == 1) {
-        if (h->taps_pad == 7) WRP_FUSED(7, 1, false); else WRP_FUSED(9, 1, false);
-    } else if (h->fused_poll == 2) {
-        if (h->taps_pad == 7) WRP_FUSED(7, 2, false); else WRP_FUSED(9, 2, false);
+        if (h->taps_pad == 7) WRP_FUSED(7, true); else WRP_FUSED(9, true);
     } else {
-        if (h->taps_pad == 7) WRP_FUSED(7, 0, false); else WRP_FUSED(9, 0, false);
+        if (h->taps_pad == 7) WRP_FUSED(7, false); else WRP_FUSED(9, false);
     }
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
@@ -326,14 +321,11 @@ int create_impl(wrp_engine *h)
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
         h->n_cus = prop.multiProcessorCount;
     }
-    h->fused_poll = (c.flags & WRP_FLAG_FUSED_POLL_LOAD) ? 1 : (c.flags & WRP_FLAG_FUSED_POLL_ATOMIC) ? 2 : 0;
-#define WRP_FUSED_ATTR(TAPS, POLL, STAMPS)                                                                      \
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<TAPS, POLL, STAMPS>), \
+#define WRP_FUSED_ATTR(TAPS, STAMPS)                                                                      \
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<TAPS, STAMPS>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES))
-    WRP_FUSED_ATTR(7, 0, false); WRP_FUSED_ATTR(9, 0, false);
-    WRP_FUSED_ATTR(7, 1, false); WRP_FUSED_ATTR(9, 1, false);
-    WRP_FUSED_ATTR(7, 2, false); WRP_FUSED_ATTR(9, 2, false);
-    WRP_FUSED_ATTR(7, 0, true);  WRP_FUSED_ATTR(9, 0, true);
+    WRP_FUSED_ATTR(7, false); WRP_FUSED_ATTR(9, false);
+    WRP_FUSED_ATTR(7, true);  WRP_FUSED_ATTR(9, true);
 #undef WRP_FUSED_ATTR
     HIP_TRY(h, hipMalloc(&h->d_ctl, sizeof(wrp::FusedCtl)));
     HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8));
@@ -417,7 +409,7 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_FUSED_POLL_LOAD | WRP_FLAG_FUSED_POLL_ATOMIC)) != 0 ||
+        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK)) != 0 ||
         ((cfg->flags & WRP_FLAG_FUSED) && (cfg->flags & WRP_FLAG_TWO_KERNELS)) || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;

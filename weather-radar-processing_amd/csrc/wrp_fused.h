@@ -115,26 +115,15 @@ __device__ __forceinline__ void l2_count32(FusedLine *lines /* wave-uniform */, 
     asm volatile("" : "+v"(l));
     if (l < FUSED_MEMBERS) __hip_atomic_fetch_add(&lines[l].w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// POLL = 0: a SCALAR load with glc (misses the scalar cache, served by the L2).  Scalar memory
-// operations have their own counter (lgkmcnt): a vector poll -- load or atomic -- returns in order
-// behind the polling wave's own tile requests, i.e. after the HBM latency of a whole tile;
-// POLL = 1: a device-scope vector load (sc1: misses the L1, served by the L2);
-// POLL = 2: an atomic add of 0 with return (performed at the L2; the zero is hidden from the
-// compiler, which otherwise folds the idempotent atomic into an sc0 load that hits the stale L1).
-template <int POLL>
+// A look at a team counter: a SCALAR load with glc (misses the scalar cache, served by the L2).
+// Scalar memory operations have their own counter (lgkmcnt): a vector poll -- load or atomic --
+// returns in order behind the polling wave's own tile requests, i.e. after the HBM latency of a
+// whole tile, and was measured 0.1 us per sector slower even where nothing is in front of it.
 __device__ __forceinline__ unsigned l2_peek(unsigned *p /* wave-uniform */)
 {
-    if (POLL == 0) {
-        unsigned v;
-        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-        return v;
-    }
-    if (POLL == 2) {
-        unsigned zero = 0;
-        asm volatile("" : "+v"(zero));
-        return __hip_atomic_fetch_add(p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
 }
 
 // control words in LDS: address space 3 spelled out, because hipcc does not infer it for volatile
@@ -142,12 +131,11 @@ __device__ __forceinline__ unsigned l2_peek(unsigned *p /* wave-uniform */)
 typedef __attribute__((address_space(3))) volatile int lds_word;
 
 // thread 0 of the workgroup: wait until *p >= target; false = gave up (status set)
-template <int POLL>
 __device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *status)
 {
 #pragma unroll 1
     for (unsigned spins = 0; spins < (1u << 22); spins++) {
-        if (l2_peek<POLL>(p) >= target) return true;
+        if (l2_peek(p) >= target) return true;
         if ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -158,36 +146,28 @@ __device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *
 // the same wait for a wave in the middle of a tile: no early return (an exit edge there costs the
 // tile loop 14 spilled registers); a wave that gave up remembers it (`failed`, wave-uniform), stops
 // waiting and runs on -- the launch is reported as failed through `status` and its output discarded
-template <int POLL>
-__device__ __forceinline__ void spin_ge_sticky(unsigned *p, unsigned target, unsigned *status, int &failed)
+// skip (wave-uniform): a wave that has nothing to wait for passes straight through, without a branch
+__device__ __forceinline__ void spin_ge_sticky(unsigned *p, unsigned target, int &failed, bool skip = false)
 {
-    if (POLL == 0) {
-        // the whole bounded loop is ONE asm statement: hipcc sees no control flow, so the registers
-        // that are live across it (a tile's worth) are not split around a loop and spilled
-        unsigned v, budget = failed ? 1u : (1u << 22);
-        asm volatile("wrp_spin%=:\n\t"
-                     "s_load_dword %0, %2, 0x0 glc\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "s_cmp_ge_u32 %0, %3\n\t"
-                     "s_cbranch_scc1 wrp_done%=\n\t"
-                     "s_sub_u32 %1, %1, 1\n\t"
-                     "s_cmp_eq_u32 %1, 0\n\t"
-                     "s_cbranch_scc1 wrp_done%=\n\t"
-                     "s_sleep 1\n\t"
-                     "s_branch wrp_spin%=\n"
-                     "wrp_done%=:"
-                     : "=&s"(v), "+s"(budget) : "s"(p), "s"(target) : "memory", "scc");
-        failed |= budget == 0;   // straight-line code here; the caller reports `failed` once, after its loop
-        return;
-    }
-    if (failed) return;
-#pragma unroll 1
-    for (unsigned spins = 0; spins < (1u << 22); spins++) {
-        if (l2_peek<POLL>(p) >= target) return;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    failed = 1;
-    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the whole bounded loop is ONE asm statement: hipcc sees no control flow, so the registers
+    // that are live across it (a tile's worth) are not split around a loop and spilled
+    unsigned v, budget = failed ? 1u : (1u << 22);
+    const unsigned have = __builtin_amdgcn_readfirstlane(skip ? 0xffffffffu : 0u);
+    asm volatile("s_cmp_ge_u32 %4, %3\n\t"
+                 "s_cbranch_scc1 wrp_done%=\n"
+                 "wrp_spin%=:\n\t"
+                 "s_load_dword %0, %2, 0x0 glc\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_cmp_ge_u32 %0, %3\n\t"
+                 "s_cbranch_scc1 wrp_done%=\n\t"
+                 "s_sub_u32 %1, %1, 1\n\t"
+                 "s_cmp_eq_u32 %1, 0\n\t"
+                 "s_cbranch_scc1 wrp_done%=\n\t"
+                 "s_sleep 1\n\t"
+                 "s_branch wrp_spin%=\n"
+                 "wrp_done%=:"
+                 : "=&s"(v), "+s"(budget) : "s"(p), "s"(target), "s"(have) : "memory", "scc");
+    failed |= budget == 0;   // straight-line code here; the caller reports `failed` once, after its loop
 }
 
 // ---- tile member: device functions -----------------------------------------------------------
@@ -298,15 +278,13 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
     }
     wave_lds_fence();
 }
-__device__ __forceinline__ void fused_stage3_store(unsigned char *smem, float2 *mid /* wave-uniform */, int col_base, int group)
+__device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
-    const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
-    const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
 #pragma unroll
     for (int it = 0; it < 2; it++) {   // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
         const int k2 = (l >> 4) + 4 * it;
@@ -315,16 +293,28 @@ __device__ __forceinline__ void fused_stage3_store(unsigned char *smem, float2 *
         for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
         fft8<-1>(a);
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
-            v2f t;
-            t.x = a[k3].x; t.y = a[k3].y;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (64 * it + 128 * k3) * DP_N * 8, 0, 0);
-        }
+        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+__device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
+{
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
+    const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
+            v2f t;
+            t.x = o[it][k3].x; t.y = o[it][k3].y;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (64 * it + 128 * k3) * DP_N * 8, 0, 0);
+        }
+}
 
-template <int TAPS, int POLL, bool STAMPS>
+template <int TAPS, bool STAMPS>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
@@ -445,21 +435,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             stamp(q, 1);
             // v is free: the next tile is requested a quarter at a time over the rest of this one
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
+            cf o[2][4];
             fused_tile_load<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
             fused_tile_load<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage3(smem, o);
             // Half 0 of the buffer holds task q-1 until every row member has those rows in registers.  The
             // hand-over cycle of a half -- stored, seen by the rows, loaded, seen here: about 4 us -- plus the
-            // way from this look to the next count bounds the task period from below, so every wave looks
-            // for itself and as late as it can: right in front of its first store.
-            spin_ge_sticky<POLL>(my_loaded0, (unsigned)(FUSED_MEMBERS * q), &ctl->status, failed);
+            // way from this look to the next count bounds the task period from below, so the look comes as
+            // late as it can: one wave looks, in front of the barrier behind which the stores go out.
+            spin_ge_sticky(my_loaded0, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
             stamp(q, 5);
-            fused_stage3_store(smem, mid, tile_col(q), 0);
-            __syncthreads();                    // A2: group 0 has left the image
+            __syncthreads();                    // A2: group 0 has left the image; half 0 of the buffer is free
+            fused_store(mid, tile_col(q), 0, o);
             // BEHIND the stores, so that a counted wait can tell them apart
             fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_group1_to_lds(smem, ga, gc);
-            stamp(q, 2);   // (placed right behind A2 this stamp makes hipcc spill 46 registers)
+            stamp(q, 2);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
             // ... and counted by the last wave to get here, without waiting for the barrier
             last = 0;
@@ -470,10 +462,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             stamp(q, 3);
             fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
-            spin_ge_sticky<POLL>(my_loaded1, (unsigned)(FUSED_MEMBERS * q), &ctl->status, failed);
+            fused_stage3(smem, o);
+            spin_ge_sticky(my_loaded1, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
             stamp(q, 7);
-            fused_stage3_store(smem, mid, tile_col(q), 1);
-            __syncthreads();                    // A4: image free for the next stage 1
+            __syncthreads();                    // A4: image free for the next stage 1; half 1 of the buffer is free
+            fused_store(mid, tile_col(q), 1, o);
             stamp(q, 4);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -501,7 +494,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             stamp(q, 0);
-            if (!spin_ge<POLL>(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) return;
+            if (!spin_ge(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) return;
             stamp(q, 1);
             cf x0[8], x1[8];
             doppler_load_row<AUX_SC1>(mid + (size_t)g0 * n, l, x0);
