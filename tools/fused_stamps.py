@@ -2,10 +2,11 @@
 """Phase anatomy of the fused launch (wrp_debug_fused_stamps, a separate diagnostic instantiation).
 Every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 8 of task 0 holds
 kind << 32 | xcc << 16 | rank.
-  tile workgroups: 0 task start, 1 stage 1 done (barrier A1), 5 quarters 0-1 requested, stages 2-3 of group 0
-                   done, half 0 seen free (wave 0), 2 A2 + stores + quarter 2 requested + group 1 written, 6 half 0
-                   drained and counted, 3 A3, 7 quarter 3 requested, stages 2-3 of group 1 done, half 1 seen free,
-                   4 A4 + stores issued
+  tile workgroups: 0 task start, 1 stage 1 done (barrier A1), [quarters 0-1 requested, stages 2-3 of group 0,
+                   half 0 seen free (wave 0), A2, stores: no stamp here -- any stamp between A1 and the
+                   stores makes hipcc spill 30-40 registers], 2 quarter 2 requested + group 1 written,
+                   6 half 0 drained and counted, 3 A3, 7 quarter 3 requested, stages 2-3 of group 1 done, half 1
+                   seen free, 4 A4 + stores issued
   row workgroups : wave 0 (half 0) slots 0-3, wave 4 (half 1) slots 4-7: + 0 task start, + 1 half stored by
                    all tiles, + 2 rows in registers and counted, + 3 rows transformed
 Read the SHARES, not the length: stamps forbid overlaps the real launch has."""
@@ -55,7 +56,7 @@ def main():
         d = np.diff(t[sel][:, r, :len(names[k]) + 1], axis=2)
         if k == 0:
             x = t[sel][:, r, :]
-            print(f"    (A1 -> stages 2-3 + look 0 {np.median(x[:, :, 5] - x[:, :, 1]):.2f}, A2 + stores + Q2 + write {np.median(x[:, :, 2] - x[:, :, 5]):.2f}, "
+            print(f"    (A1 -> stages 2-3 + look 0 + A2 + stores + Q2 + write {np.median(x[:, :, 2] - x[:, :, 1]):.2f}, "
                   f"drain + count {np.median(x[:, :, 6] - x[:, :, 2]):.2f}, barrier A3 {np.median(x[:, :, 3] - x[:, :, 6]):.2f}, "
                   f"A3 -> stages 2-3 + look 1 {np.median(x[:, :, 7] - x[:, :, 3]):.2f}, A4 + stores {np.median(x[:, :, 4] - x[:, :, 7]):.2f})")
         print(f"{label} workgroups ({int(sel.sum())}), tasks 3..{tasks - 1}; median (p10 .. p90) us")

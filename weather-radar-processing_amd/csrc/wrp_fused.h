@@ -445,7 +445,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             // way from this look to the next count bounds the task period from below, so the look comes as
             // late as it can: one wave looks, in front of the barrier behind which the stores go out.
             spin_ge_sticky(my_loaded0, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
-            stamp(q, 5);
             __syncthreads();                    // A2: group 0 has left the image; half 0 of the buffer is free
             fused_store(mid, tile_col(q), 0, o);
             // BEHIND the stores, so that a counted wait can tell them apart
