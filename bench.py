@@ -7,17 +7,25 @@ n=512, fp32 complex) that is ALREADY RESIDENT IN HBM when the timed region start
 sector of the sweep has its own 8 MiB of device memory (2.95 GiB per sweep, >> the 256 MiB
 Infinity Cache), so re-reads cannot be served on-die.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--sectors S] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--sectors S] [--no-cpu-baseline] [--no-end-to-end]
 
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; sectors are
 sharded by rank with NO data-path collective (weak scaling: every GPU owns a full sweep);
-torch.distributed only provides the barrier and the MAX over ranks of the elapsed time.
+torch.distributed (gloo: control plane only) provides the barrier and the MAX over ranks of the
+elapsed time.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the field definitions).
+Prints ONE JSON line on rank 0 (DESIGN.md 6 defines the fields):
+  value        device-resident sectors/s (PCIe not included) -- BASELINE.json's kernel-only figure
+  roofline     of the dominant launch, from HIP events on the engine's own stream in this run;
+               `traffic` from the rocprofv3 PMC run of the SAME library sources (fingerprint checked)
+  end_to_end   sectors/s through the 4-slot cascade: pinned H2D of the wire-format sector + decode +
+               chain + D2H per sector, all ranks at once -- BASELINE.json's end-to-end figure
+  cpu_baseline the oracle's fp32 port on this host's cores (all usable cores and one thread)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,40 +34,80 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_ROUND = "r02"
 
 
-def cpu_baseline(m, n, budget_s=12.0):
-    """Time the oracle's fp32 port (OpenMP) on this host: a bounded sample of the same workload."""
+def host_cpus():
+    """Usable logical CPUs, physical cores among them and the model string (/proc/cpuinfo)."""
+    usable = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in usable:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    model = cur.get("model name", model)
+                cur = {}
+    except OSError:
+        pass
+    return len(usable), max(len(cores), 1), model
+
+
+def cpu_baseline_child(threads, budget_s):
+    """Runs in a FRESH process whose OMP_NUM_THREADS was set before anything was imported."""
     import numpy as np
     from oracle import oracle as O
-    cores = min(os.cpu_count() or 1, 16)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     O.build()
+    m, n = 1024, 512
     iq = O.synthetic_sector(0, m, n)
     coef = O.hamming_coef(m, n, np.float32)
     O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)            # warm-up
     t0 = time.perf_counter()
     O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)
     one = time.perf_counter() - t0
-    cnt = max(3, min(400, int(budget_s / max(one, 1e-4))))
+    cnt = max(3, min(5000, int(budget_s / max(one, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(cnt):
         O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)
     dt = time.perf_counter() - t0
-    return {"value": round(cnt / dt, 2), "unit": "sectors/s", "cores": cores, "kind": "port",
-            "sample": f"{cnt} sectors of the same shape (oracle/radar_oracle.c fp32, OpenMP {cores} threads, "
-                      f"{dt:.1f} s)"}
+    print(json.dumps({"sectors": cnt, "seconds": dt}))
+
+
+def cpu_baseline():
+    logical, physical, model = host_cpus()
+    threads = min(logical, 16)          # 16 = the CPU share of a one-GPU box; stated in `sample`
+
+    def run(t, budget):
+        env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PROC_BIND="close")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(t), str(budget)],
+                             env=env, capture_output=True, text=True, timeout=300)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        return r["sectors"] / r["seconds"], r
+    allc, ra = run(threads, 10.0)
+    one, r1 = run(1, 8.0)
+    return {"value": round(allc, 2), "unit": "sectors/s", "cores": threads, "kind": "port",
+            "one_thread": round(one, 2), "physical_cores": physical, "logical_cpus": logical, "cpu_model": model,
+            "sample": f"{ra['sectors']} sectors of the same shape on {threads} OpenMP threads ({ra['seconds']:.1f} s; "
+                      f"min(usable logical CPUs, 16)) and {r1['sectors']} sectors on 1 thread ({r1['seconds']:.1f} s); "
+                      f"oracle/radar_oracle.c fp32 port, each in a fresh process"}
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_child(int(sys.argv[2]), float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is 1.25 ms: the defaults keep the GPU busy for ~0.3 s so that its clocks have settled
+    # a step is ~1 ms: the defaults keep the GPU busy for ~0.3 s so that its clocks have settled
+    # (with --steps 20 the same binary reads about 5 % lower: DESIGN.md 6)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--sectors", type=int, default=360, help="sectors per step per GPU (one elevation sweep)")
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("WRP_MAX_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,30 +123,26 @@ def main():
     dev_index = local_rank % max(ngpu, 1)     # one rank per GPU; wraps only when rehearsed on a smaller box
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    ctl_dev = dev                              # device of the control-plane tensors (barrier / MAX)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # control plane only (barrier + MAX of the elapsed time): RCCL when every rank has its own
-        # GPU, gloo otherwise (RCCL refuses two ranks on one device)
-        if ngpu >= world:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            ctl_dev = torch.device("cpu")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        # control plane only (barrier + MAX of the elapsed time): gloo on CPU tensors; the data path has
+        # no collective and RCCL is never initialised (north_star)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     m, n, C = 1024, 512, 2
     S = args.sectors
-    cfg = dict(n_slots=1, n_sectors=1, n_elevations=1)
+    SLOTS = 4
+    cfg = dict(n_slots=SLOTS, n_sectors=S, n_elevations=1)
     if args.max_batch > 0:
         cfg["max_batch"] = args.max_batch
-    if os.environ.get("WRP_FLAGS"):          # A/B measurements only (e.g. 0x100 = fused launch)
+    if os.environ.get("WRP_FLAGS"):          # A/B measurements only (e.g. 0x800 = two kernels)
         cfg["flags"] = int(os.environ["WRP_FLAGS"], 0)
     eng = wrp_amd.Engine(device=dev_index, **cfg)
 
-    # synthetic sweep: a pool of 8 distinct sectors (SURVEY §8d generator), replicated on the
+    # synthetic sweep: a pool of 8 distinct sectors (SURVEY 8d generator), replicated on the
     # device into S distinct 8 MiB blocks; sector index = rank*S + k so ranks see different data
     pool = np.stack([O.synthetic_sector((rank * S + k) % 4096, m, n, C) for k in range(8)])
     d_pool = torch.from_numpy(pool.view(np.float32).reshape(8, -1)).to(dev)
@@ -116,6 +160,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -123,18 +174,17 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    eng.check()                               # a fused launch that gave up would be reported here
 
-    # correctness spot check on what was just computed (first sector of the sweep)
-    got = d_out[0].cpu().numpy()
-    want = O.sector(pool[0][0], pool[0][1], dtype=np.float64)
-    ok = bool(np.isneginf(got[0, 0]) and np.max(np.abs(got[1:] - want[1:])) < 1e-3)
+    # correctness spot check on what was just computed (first and last sector of the sweep)
+    ok = True
+    for k in (0, S - 1):
+        got = d_out[k].cpu().numpy()
+        want = O.sector(pool[k % 8][0], pool[k % 8][1], dtype=np.float64)
+        ok = ok and bool(np.isneginf(got[0, 0]) and np.max(np.abs(got[1:] - want[1:])) < 1e-3)
 
-    # roofline of the fused chain: HIP events on the engine's own stream around the same launches
+    # roofline of the dominant launch: HIP events on the engine's own stream around the same launches
     # (the GPU has idled during the host-side spot check: bring the clocks back up first, untimed)
     iters = max(3, min(args.steps, 20))
     for _ in range(max(args.warmup, 10)):
@@ -143,29 +193,70 @@ def main():
     algo = eng.algorithmic_bytes
     t_sector = ms_total * 1e-3 / (iters * S)
     achieved = algo / t_sector / 1e9
-    max_batch = eng.lib.wrp_get_config  # noqa: F841  (config is echoed below)
     c2 = wrp_amd.WrpConfig()
     eng.lib.wrp_get_config(eng.handle, c2)
-    launches = -(-S // c2.max_batch)
-    # HBM traffic per launch pair from the committed rocprofv3 PMC run of this same configuration
-    # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; profiles/r01/traffic.json)
-    traffic = None
+    fused = (c2.flags & wrp_amd.FLAG_TWO_KERNELS) == 0 and S >= wrp_amd.FUSED_MIN_SECTORS
+    per_launch = S if fused else min(S, c2.max_batch)
+    launches = 1 if fused else -(-S // c2.max_batch)
+    kernel = ("fused_chain_1024x512 (one persistent launch per sweep: tile + row workgroups, intermediate in the XCDs' L2)"
+              if fused else "range_pass_1024_persistent + doppler_pass_512 (one launch pair per chunk)")
+    # HBM traffic per launch from the rocprofv3 PMC run of the SAME library sources (FETCH_SIZE / WRITE_SIZE in
+    # separate passes, gfx950 correction applied; tools/profile_pmc.sh -> tools/make_traffic.py).  The file
+    # records a fingerprint of csrc/, include/ and the compiler flags: anything else reads null.
+    traffic, traffic_note = None, "no traffic file for this build"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-        if tj["sectors_per_launch"] == c2.max_batch and c2.flags == 0:
-            traffic = round(tj["bytes_per_launch_pair"])
+        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))
+        if tj.get("fingerprint") != wrp_amd.source_fingerprint():
+            traffic_note = "profiles/%s/traffic.json was measured on other sources (fingerprint differs)" % PROFILE_ROUND
+        elif tj.get("sectors_per_launch") != per_launch or tj.get("fused") != fused:
+            traffic_note = "profiles/%s/traffic.json was measured on another configuration" % PROFILE_ROUND
+        else:
+            traffic = round(tj["bytes_per_launch"])
+            traffic_note = tj.get("source", "")
     except Exception:
         pass
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "algorithmic_bytes_per_launch_pair": algo * min(S, c2.max_batch),
-        "kernel": "range_pass_1024 + doppler_pass_512 (one launch pair per chunk)",
-        "algorithmic_bytes_per_sector": algo, "sectors_per_launch": c2.max_batch,
-        "avg_launch_pair_us": round(ms_total * 1e3 / (iters * launches), 2),
-        "range_pass_us_per_sector": round(ms_range * 1e3 / (iters * S), 3),
-        "doppler_pass_us_per_sector": round(ms_dopp * 1e3 / (iters * S), 3),
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+        "kernel": kernel, "algorithmic_bytes_per_sector": algo, "sectors_per_launch": per_launch,
+        "algorithmic_bytes_per_launch": algo * per_launch,
+        "avg_launch_us": round(ms_total * 1e3 / (iters * launches), 2),
     }
+    if not fused:
+        roofline["range_pass_us_per_sector"] = round(ms_range * 1e3 / (iters * S), 3)
+        roofline["doppler_pass_us_per_sector"] = round(ms_dopp * 1e3 / (iters * S), 3)
+
+    # end to end: every sector crosses PCIe.  Wire-format sector (12 B/sample, big-endian int16, 6 MiB) in
+    # the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB, 4 slots cascading, all ranks at once.
+    end_to_end = None
+    if not args.no_end_to_end:
+        w = np.zeros((m * n, 6), dtype=">i2")
+        for c in range(2):
+            w[:, 2 * c] = pool[0][c].real.ravel()
+            w[:, 2 * c + 1] = pool[0][c].imag.ravel()
+        raw = np.frombuffer(w.tobytes(), np.uint8)
+        for s in range(SLOTS):
+            eng.raw_slot_array(s)[:] = raw
+        dt = 0.0
+        for rep in range(2):                  # the second repetition is the one reported
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(S):
+                s = k % SLOTS
+                if k >= SLOTS:
+                    eng.wait(s)
+                eng.submit_raw(s, k, 0)
+            for s in range(min(SLOTS, S)):
+                eng.wait(s)
+            barrier()
+            dt = max_over_ranks(time.perf_counter() - t0)
+        want = O.sector(pool[0][0], pool[0][1], dtype=np.float64)
+        e_ok = bool(np.max(np.abs(eng.result(S - 1, 0)[1:] - want[1:])) < 1e-3)
+        end_to_end = {"value": round(world * S / dt, 1), "unit": "sectors/s", "slots": SLOTS, "sectors_per_gpu": S,
+                      "ingest": "wire format, 12 B/sample big-endian int16 (6 MiB/sector), decoded on the GPU",
+                      "h2d_GBps_per_gpu": round(S * m * n * 12 / dt / 1e9, 1), "spot_check_vs_oracle": e_ok,
+                      "includes": "pinned H2D + decode + range/Doppler kernels + D2H per sector; host refill of the pinned "
+                                  "slots not included"}
 
     total_sectors = world * S * args.steps
     line = {
@@ -177,13 +268,16 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"00iq.altb shape (C=2, m=1024, n=512, fp32 complex), {S}-sector elevation "
                                f"sweep per GPU per step, device-resident", "sectors_per_step_per_gpu": S,
-                   "parallelism": f"sector-sharded x{world}, no collective"},
+                   "parallelism": f"sector-sharded x{world}, no collective (gloo barrier + MAX only)",
+                   "launch": "fused" if fused else "two kernels"},
         "achieved_hbm_GBps": round(world * achieved, 1),
         "spot_check_vs_oracle": ok,
         "roofline": roofline,
     }
+    if end_to_end is not None:
+        line["end_to_end"] = end_to_end
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(m, n)
+        line["cpu_baseline"] = cpu_baseline()
     eng.close()
     if dist is not None:
         dist.barrier()

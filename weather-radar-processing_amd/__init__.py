@@ -22,4 +22,5 @@ from .binding import (  # noqa: F401
     header_symbols,
     lib_path,
     load_library,
+    source_fingerprint,
 )

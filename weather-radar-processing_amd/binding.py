@@ -41,6 +41,23 @@ def STAGE_SHAPES(m, n):
     }
 
 
+def source_fingerprint():
+    """sha256 over the sources libwrp.so is built from (csrc/, include/wrp.h, the Makefile's flags): ties a
+    committed rocprof summary (profiles/rNN/traffic.json) to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(os.path.join(_PKG, "csrc")))
+    for f in files:
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(_PKG, "csrc", f), "rb").read())
+    h.update(open(os.path.join(_ROOT, "include", "wrp.h"), "rb").read())
+    for line in open(os.path.join(_ROOT, "Makefile")):
+        if line.startswith("HIPFLAGS"):
+            h.update(line.encode())
+    return h.hexdigest()[:16]
+
+
 def lib_path():
     return os.path.join(_PKG, "lib", "libwrp.so")
 
