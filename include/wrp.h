@@ -172,6 +172,12 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
 int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                            unsigned long long *host_stamps, size_t host_count);
 
+/* Parity of the intermediate: one fused launch over n_sectors >= WRP_FUSED_MIN_SECTORS sectors, then the
+ * teams' L2-resident buffers copied to host_mid[8][m/2][n] complex fp32: buffer x holds the range-FFT
+ * gates < m/2 of the LAST channel-task of the team on XCD x (VV of the last sector that team owns; with
+ * n_sectors = 8 on an 8-XCD device: sector x).  Must equal wrp_dump_stage(02FFT1) bit for bit. */
+int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *host_mid, size_t host_bytes);
+
 /* Introspection for harnesses. */
 int wrp_get_config(wrp_handle h, wrp_config *cfg);
 size_t wrp_sector_bytes(wrp_handle h);   /* channels*m*n*8 */

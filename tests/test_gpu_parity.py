@@ -4,7 +4,7 @@ Tolerances (fp32 path vs the fp64 oracle), SURVEY.md §8(d2):
   stage arrays : |a-b| <= 1e-5*|b| + 1e-5*rowmax|b| per element and ||a-b||/||b|| <= 1e-6
                  (04abs: post-shift DC column n/2 excluded -- rounding noise in the reference's
                  own cpu/gpu dumps);
-  Zdb / Zdr    : 1e-5 relative on Zdb, 1e-4 dB absolute on Zdr (a difference of logs, ~0);
+  Zdb / Zdr    : 1e-5 relative on Zdb, 2e-5 dB absolute on Zdr (a difference of logs, ~0; measured 9e-6);
                  gate 0 must be -inf in both.
 """
 import numpy as np
@@ -50,7 +50,7 @@ def check_final(got, want):
     rel = np.max(np.abs(got[1:, 0] - want[1:, 0]) / np.abs(want[1:, 0]))
     adr = np.max(np.abs(got[:, 1] - want[:, 1]))
     assert rel < 1e-5, rel
-    assert adr < 1e-4, adr
+    assert adr < 2e-5, adr
 
 
 def test_single_sector_final_outputs(engine, oracle, sectors):
@@ -159,6 +159,28 @@ def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, oracle, sectors):
         assert np.array_equal(ef.process_host(batch[:3]), b[:3])
 
 
+def test_fused_intermediate_equals_the_dumped_range_fft(wrp, sectors):
+    """The stage dumps come from the two-kernel form; the fused launch keeps its intermediate in the XCDs' L2.
+    Its buffers after a launch over 8 sectors (one per XCD team) must hold, bit for bit, the rows < m/2 of the
+    dumped 02fft1 stage of each team's VV channel: the dumps describe the launch the bench times."""
+    import ctypes as C
+    import torch
+    batch = np.stack([sectors[k % 3] * np.float32(1 + 0.125 * k) for k in range(8)])
+    d_in = torch.from_numpy(batch.view(np.float32)).cuda()
+    d_out = torch.zeros(8, M // 2, 2, device="cuda")
+    mid = np.zeros((8, M // 2, N), np.complex64)
+    with wrp.Engine(device=0, n_slots=1) as e:
+        rc = e.lib.wrp_debug_fused_mid(e.handle, C.c_void_p(d_in.data_ptr()), 8, C.c_void_p(d_out.data_ptr()),
+                                       mid.ctypes.data_as(C.c_void_p), mid.nbytes)
+        assert rc == 0, e.lib.wrp_last_hip_error(e.handle)
+        for k in (0, 3, 7):
+            e.slot_array(0)[:] = batch[k]
+            e.submit(0, 0, 0)
+            e.wait(0)
+            fft1 = e.dump_stage(0, "02fft1", 1)[: M // 2]
+            assert np.array_equal(mid[k].view(np.uint32), fft1.view(np.uint32)), k
+
+
 def test_fused_launch_through_the_device_entry_and_check(wrp, sectors):
     """wrp_process_batch_device is asynchronous: wrp_check reports a fused launch that gave up.  Here it
     must report success, on the engine's stream and on a caller's stream, back to back (one batch in
@@ -231,7 +253,7 @@ def test_special_values_compare_by_class(wrp, oracle, sectors):
         for cls in (np.isnan, np.isposinf, np.isneginf):
             assert np.array_equal(cls(got), cls(want)), (flags, cls.__name__)
         fin = np.isfinite(want)
-        assert np.max(np.abs(got[fin] - want[fin])) < 1e-3, flags          # dB
+        assert np.max(np.abs(got[fin] - want[fin])) < 1e-4, flags          # dB
         assert np.array_equal(got[0], got[5]) and np.array_equal(got[0], got[8])
     assert np.all(np.isneginf(want[1, :, 0])) and np.all(np.isnan(want[1, :, 1]))
     assert np.all(np.isposinf(want[2, 1:, 1]))

@@ -715,6 +715,20 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
     return rc;
 }
 
+int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *host_mid, size_t host_bytes)
+{
+    if (!h || !d_iq || !d_out || !host_mid || n_sectors < WRP_FUSED_MIN_SECTORS) return WRP_ERR_INVALID;
+    if (!h->tuned) return WRP_ERR_UNSUPPORTED;
+    const size_t bytes = sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8;
+    if (host_bytes < bytes) return WRP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = launch_fused(h, (const float2 *)d_iq, n_sectors, d_out, h->stream);
+    if (rc != WRP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(host_mid, h->d_mid_pool, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return check_fused(h);
+}
+
 int wrp_get_config(wrp_handle h, wrp_config *cfg)
 {
     if (!h || !cfg) return WRP_ERR_INVALID;
