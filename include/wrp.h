@@ -81,6 +81,10 @@ typedef struct {
  * one-tile-per-workgroup form instead (same arithmetic, bit-identical results; A/B only). */
 #define WRP_FLAG_ONE_TILE_PER_BLOCK 0x400
 
+/* test hook: the fused launch is issued with half its workgroups, so that it must report (wrp_check)
+ * that its teams are incomplete and the handle must fall back to the two kernels */
+#define WRP_FLAG_DEBUG_FUSED_UNDERSIZED 0x4000
+
 /* Stage ids for wrp_dump_stage; names follow the reference's fixture files. */
 typedef enum {
     WRP_STAGE_01HAMM = 1,         /* m x n complex  after the Hamming window          (a2) */

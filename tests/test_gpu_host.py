@@ -48,3 +48,97 @@ def test_rpv2_file_replay(tmp_path, oracle, streams):
                 assert np.max(np.abs(vals[1:] - want[1:, 0]) / np.abs(want[1:, 0])) < 1e-5
             else:
                 assert np.max(np.abs(vals - want[:, 1])) < 2e-5
+
+
+def parse_frames(raw, header):
+    """frames of `header` + 512 big-endian floats -> {(which-th frame of (sector, elev)): values}"""
+    frame = header + 4 * 512
+    assert raw.size % frame == 0
+    out = {}
+    for k in range(raw.size // frame):
+        fr = raw[k * frame:(k + 1) * frame]
+        sector = (int(fr[0]) << 8) | int(fr[1])
+        elev = ((int(fr[2]) << 8) | int(fr[3])) if header == 4 else 0
+        out.setdefault((elev, sector), []).append(fr[header:])
+    return out
+
+
+def test_rpv2_two_gpu_threads_share_one_source(tmp_path, oracle):
+    """--devices 0,0: two host threads, two engine handles (here on the one GPU there is), sector s of every
+    elevation to thread s mod 2, one source read in acquisition order through the turnstile.  Every sector of
+    the scan comes out exactly once, with the values of the single-thread run (configs[3]'s host side)."""
+    assert os.path.exists(RPV2), "run `make host`"
+    K, SECT, ELEV = 11, 4, 3                      # 11 sectors of a 4 x 3 scan: the last elevation stays incomplete
+    sectors = [oracle.synthetic_sector(s) for s in range(3)]
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        for k in range(K):
+            f.write(wire_bytes(sectors[k % 3]))
+    r = subprocess.run([RPV2, "3", "--devices", "0,0", "--scan", f"{SECT},{ELEV}", "--in", f"file:{fin}", "--out", f"file:{fout}",
+                        "--sectors", str(K)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"{K} sectors processed" in r.stderr and "2 GPU threads" in r.stderr
+    assert "shard 0 of 2): 6 sectors" in r.stderr and "shard 1 of 2): 5 sectors" in r.stderr
+    got = parse_frames(np.fromfile(fout, dtype=np.uint8), 4)
+    want_keys = {(k // SECT, k % SECT) for k in range(K)}
+    assert set(got) == want_keys
+    ref = [oracle.sector(s[0], s[1], dtype=np.float64) for s in sectors]
+    for k in range(K):
+        fr = got[(k // SECT, k % SECT)]
+        assert len(fr) == 2                                          # Zdb frame, then Zdr frame
+        zdb, zdr = oracle.abtoaf(fr[0]), oracle.abtoaf(fr[1])
+        w = ref[k % 3]
+        assert np.isneginf(zdb[0]) and np.max(np.abs(zdb[1:] - w[1:, 0]) / np.abs(w[1:, 0])) < 1e-5
+        assert np.max(np.abs(zdr - w[:, 1])) < 2e-5
+
+
+def test_rpv2_udp_ingest_and_egress_on_loopback(oracle):
+    """N3, the UDP half: m datagrams of 12 n bytes per sector to port IN (read_single.cc:145-148), products back as
+    one datagram per product with the 2-byte sector header (read_single.cc:510-520), here unicast to 127.0.0.1."""
+    import socket
+    import threading
+    import time
+    assert os.path.exists(RPV2), "run `make host`"
+    IN, ZDB, ZDR, K = 19411, 19412, 19413, 3
+    sectors = [oracle.synthetic_sector(s) for s in range(K)]
+    rx = []
+    for port in (ZDB, ZDR):
+        s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        s.bind(("127.0.0.1", port))
+        s.settimeout(60)
+        rx.append(s)
+    proc = subprocess.Popen([RPV2, "2", "--in", f"udp:{IN}", "--out", f"udp:{ZDB},{ZDR}@127.0.0.1", "--sectors", str(K)],
+                            stderr=subprocess.PIPE, text=True)
+    got = {0: [], 1: []}
+
+    def receive(which):
+        for _ in range(K):
+            got[which].append(np.frombuffer(rx[which].recvfrom(65536)[0], np.uint8))
+    threads = [threading.Thread(target=receive, args=(w,)) for w in (0, 1)]
+    for t in threads:
+        t.start()
+    tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    line = proc.stderr.readline()                  # the engine (and its socket) come up first
+    assert "ready" in line, line
+    row = 12 * 512
+    for iq in sectors:
+        b = wire_bytes(iq)
+        for i in range(1024):
+            tx.sendto(b[i * row:(i + 1) * row], ("127.0.0.1", IN))
+            if i % 8 == 7:
+                time.sleep(0.001)                  # loop-back has no flow control: do not overrun the receive buffer
+    for t in threads:
+        t.join(90)
+    err = proc.communicate(timeout=60)[1]
+    assert proc.returncode == 0, err
+    assert all(len(got[w]) == K for w in (0, 1)), (len(got[0]), len(got[1]), err)
+    for k in range(K):
+        want = oracle.sector(sectors[k][0], sectors[k][1], dtype=np.float64)
+        for which in (0, 1):
+            fr = got[which][k]
+            assert fr.size == 2 + 4 * 512 and list(fr[:2]) == [0, k]
+            vals = oracle.abtoaf(fr[2:])
+            if which == 0:
+                assert np.isneginf(vals[0]) and np.max(np.abs(vals[1:] - want[1:, 0]) / np.abs(want[1:, 0])) < 1e-5
+            else:
+                assert np.max(np.abs(vals - want[:, 1])) < 2e-5

@@ -202,6 +202,33 @@ def test_fused_launch_through_the_device_entry_and_check(wrp, sectors):
     assert np.array_equal(d_b.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_fused_launch_that_cannot_form_its_teams_is_reported(wrp, sectors):
+    """A fused launch whose workgroups are not all there (here: launched with half of them; in the field: another
+    kernel holding CUs) must say so instead of delivering garbage: the asynchronous entry reports it through
+    wrp_check, once, and the handle runs the two kernels from then on; the synchronous entry repeats the batch
+    by itself and returns the right answer."""
+    import torch
+    count = 12
+    batch = np.stack([sectors[k % 3] * np.float32(1 + k) for k in range(count)])
+    d_in = torch.from_numpy(batch.view(np.float32)).cuda()
+    d_out = torch.zeros(count, M // 2, 2, device="cuda")
+    with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
+        want = e2.process_host(batch)
+    with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:
+        e.process_batch_device(d_in.data_ptr(), count, d_out.data_ptr())
+        with pytest.raises(wrp.WrpError) as err:
+            e.check()
+        assert "32 tile + 32 row" in str(err.value)
+        e.check()                                                   # reported once
+        e.process_batch_device(d_in.data_ptr(), count, d_out.data_ptr())      # now the two kernels
+        e.check()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:
+        assert np.array_equal(e.process_host(batch).view(np.uint32), want.view(np.uint32))
+        assert b"two-kernel path" in e.lib.wrp_last_hip_error(e.handle)
+
+
 def test_wire_format_ingest_is_bit_identical_to_cpu_decode(wrp, oracle):
     """N1: raw 12 B/sample big-endian int16 upload + GPU decode == Sector::fromByteArray + the
     int16->float2 scatter of rpv2.cu:369-383 (oracle restatement, itself pinned by the reference's

@@ -218,8 +218,10 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
+    // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
+    const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
 #define WRP_FUSED(TAPS, STAMPS)                                                                                       \
-    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(h->n_cus * 2), dim3(wrp::FUSED_THREADS),       \
+    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
     if (d_stamps) {
@@ -409,7 +411,7 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK)) != 0 ||
+        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED)) != 0 ||
         ((cfg->flags & WRP_FLAG_FUSED) && (cfg->flags & WRP_FLAG_TWO_KERNELS)) || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;

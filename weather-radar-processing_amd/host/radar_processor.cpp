@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "framing.h"
 
 RadarProcessor::RadarProcessor(int num_sectors, int num_sweeps, int num_samples, int num_elevations, int num_streams)
@@ -30,7 +32,9 @@ void RadarProcessor::set_comms(int in_port, int *out_ports, int n_out)
     // radar_processor.cu:59-68: one UDP server for ingest, one client per product
     server_.reset(new udpbroadcast::udpserver(in_port));
     clients_.clear();
-    for (int i = 0; i < n_out; i++) clients_.emplace_back(new udpbroadcast::udpclient(out_ports[i]));
+    for (int i = 0; i < n_out; i++)
+        clients_.emplace_back(unicast_.empty() ? new udpbroadcast::udpclient(out_ports[i])
+                                               : new udpbroadcast::udpclient(out_ports[i], unicast_.c_str()));
     source_ = [this](char *buf, size_t bytes) {
         // one datagram per range row: m datagrams of 12*n bytes (read_single.cc:145-148)
         const size_t row = (size_t)NUM_BYTES_PER_SAMPLE * n_samples;
@@ -50,7 +54,10 @@ int RadarProcessor::start()
     generate_constants();
     prepare_arys();
     initialize_streams();
+    if (status_ == WRP_OK && on_ready_) on_ready_();
+    const auto t0 = std::chrono::steady_clock::now();
     if (status_ == WRP_OK) do_process();
+    seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     destroy_streams();
     destroy_arrays();
     return status_;
@@ -78,13 +85,28 @@ void RadarProcessor::initialize_streams()
     status_ = wrp_create(&cfg, device_, &eng_);
 }
 
-bool RadarProcessor::read_matrix(int, int, int stream)
+bool RadarProcessor::read_matrix(int sector, int elevation, int stream)
 {
     void *raw = nullptr;
     size_t bytes = 0;
     status_ = wrp_pinned_raw_slot(eng_, stream, &raw, &bytes);
     if (status_ != WRP_OK) return false;
-    return source_((char *)raw, bytes);      // no CPU decode, no int16->float scatter (rpv2.cu:364-383)
+    if (!turn_) return source_((char *)raw, bytes);      // no CPU decode, no int16->float scatter (rpv2.cu:364-383)
+    // sharded scan: wait until it is this sector's turn on the shared source, read it straight into
+    // this GPU's pinned slot, pass the turn on
+    const long seq = (laps_ * n_elevations + elevation) * (long)n_sectors + sector;
+    std::unique_lock<std::mutex> lk(turn_->mu);
+    turn_->cv.wait(lk, [&] { return turn_->ended || turn_->next == seq; });
+    if (turn_->ended) return false;
+    if (max_sectors_ >= 0 && seq >= max_sectors_) {       // the scan's sector budget (a GLOBAL count) is used up
+        turn_->ended = true;
+        turn_->cv.notify_all();
+        return false;
+    }
+    const bool ok = source_((char *)raw, bytes);
+    if (ok) turn_->next = seq + 1; else turn_->ended = true;
+    turn_->cv.notify_all();
+    return ok;
 }
 
 void RadarProcessor::copy_matrix_to_device(int sector, int elevation, int stream)
@@ -98,9 +120,13 @@ void RadarProcessor::perform_stage_3(int) {}
 
 void RadarProcessor::advance()
 {
-    // rpv2.cu:572-579
-    current_sector = (current_sector + 1) % n_sectors;
-    if (current_sector == 0) current_elevation = (current_elevation + 1) % n_elevations;
+    // rpv2.cu:572-579; sharded: this processor's next sector is `world` further on
+    current_sector += shard_world_;
+    if (current_sector >= n_sectors) {
+        current_sector = shard_rank_;
+        current_elevation = (current_elevation + 1) % n_elevations;
+        if (current_elevation == 0) laps_++;
+    }
     current_stream = (current_stream + 1) % n_streams;
 }
 
@@ -115,6 +141,8 @@ void RadarProcessor::send_results(int sector, int elevation)
     status_ = wrp_result(eng_, sector, elevation, &r);
     if (status_ != WRP_OK || !sink_) return;
     std::vector<unsigned char> frame(4 * (size_t)output_rows + 4);
+    std::unique_lock<std::mutex> lk;
+    if (turn_) lk = std::unique_lock<std::mutex>(turn_->sink_mu);
     for (int which = 0; which < 2; which++) {
         const size_t n = frame_result(r, output_rows, sector, elevation, which, with_elevation_, frame.data());
         sink_(which, sector, elevation, frame.data(), n);
@@ -128,8 +156,11 @@ void RadarProcessor::do_process()
     struct InFlight { int sector, elevation, stream; };
     std::vector<InFlight> q;
     bool more = true;
+    current_sector = shard_rank_;
+    if (current_sector >= n_sectors) more = false;          // more GPUs than sectors: nothing to do here
+    const bool own_budget = turn_ == nullptr;               // sharded: the budget is global, read_matrix enforces it
     while (status_ == WRP_OK && (more || !q.empty())) {
-        if (more && (int)q.size() < n_streams && (max_sectors_ < 0 || done_ + (long)q.size() < max_sectors_)) {
+        if (more && (int)q.size() < n_streams && (!own_budget || max_sectors_ < 0 || done_ + (long)q.size() < max_sectors_)) {
             if (read_matrix(current_sector, current_elevation, current_stream) && status_ == WRP_OK) {
                 copy_matrix_to_device(current_sector, current_elevation, current_stream);
                 perform_stage_1(current_stream);
@@ -149,7 +180,7 @@ void RadarProcessor::do_process()
         if (status_ != WRP_OK) break;
         send_results(f.sector, f.elevation);
         done_++;
-        if (max_sectors_ >= 0 && done_ + (long)q.size() >= max_sectors_) more = false;
+        if (own_budget && max_sectors_ >= 0 && done_ + (long)q.size() >= max_sectors_) more = false;
     }
 }
 

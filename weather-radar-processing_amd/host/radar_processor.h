@@ -12,8 +12,11 @@
 #define WRP_HOST_RADAR_PROCESSOR_H
 #include <stddef.h>
 
+#include <condition_variable>
 #include <functional>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "udpbroadcast.h"
@@ -21,12 +24,26 @@
 
 #define NUM_BYTES_PER_SAMPLE (3 * 2 * 2)
 
+// Several RadarProcessors -- one per GPU, each on its own host thread -- share ONE source (a socket
+// delivers the sectors of a volume scan in acquisition order).  The turnstile hands the source to the
+// processor that owns the next sector (sector s of every elevation belongs to processor s mod G,
+// SURVEY 8e) and to nobody else; everything behind the read (H2D, kernels, D2H, egress) runs in
+// parallel on the G GPUs.  No data-path exchange between the GPUs, hence no collective.
+struct SectorTurnstile {
+    std::mutex mu;
+    std::condition_variable cv;
+    long next = 0;        // global sequence number (elevation * n_sectors + sector) of the sector to be read next
+    bool ended = false;   // the source is exhausted (or failed): nobody reads any more
+    std::mutex sink_mu;   // frames of different GPUs leave through one sink, one frame at a time
+};
+
 class RadarProcessor {
   public:
     RadarProcessor(int num_sectors, int num_sweeps, int num_samples, int num_elevations, int num_streams);
     ~RadarProcessor();
     int start();
     void set_comms(int in_port, int *out_ports, int n_out);   // UDP: in_port raw sectors, out_ports[0] Zdb, [1] Zdr
+    void set_unicast(const char *ipv4) { unicast_ = ipv4 ? ipv4 : ""; }   // products to this host instead of the broadcast address
 
     // hooks the reference does not have (tests, file replay, other transports)
     typedef std::function<bool(char *buf, size_t bytes)> Source;   // one sector of wire bytes; false = end
@@ -34,9 +51,14 @@ class RadarProcessor {
     void set_source(Source s) { source_ = std::move(s); }
     void set_sink(Sink s) { sink_ = std::move(s); }
     void set_device(int d) { device_ = d; }
+    // this processor owns the sectors s with s % world == rank of every elevation (world GPUs, one
+    // processor each); the processors of one scan share `turn`
+    void set_shard(int rank, int world, SectorTurnstile *turn) { shard_rank_ = rank; shard_world_ = world; turn_ = turn; }
     void set_max_sectors(long n) { max_sectors_ = n; }
+    void set_on_ready(std::function<void()> f) { on_ready_ = std::move(f); }   // called once the engine exists and the loop starts
     void set_frame_with_elevation(bool on) { with_elevation_ = on; }
     long sectors_done() const { return done_; }
+    double processing_seconds() const { return seconds_; }   // wall clock of do_process (engine set-up excluded)
     const char *last_error() const;
 
     const int input_ary_size, input_columns, input_rows, output_ary_size, output_columns, output_rows;
@@ -52,10 +74,16 @@ class RadarProcessor {
 
     wrp_handle eng_ = nullptr;
     int device_ = 0;
+    int shard_rank_ = 0, shard_world_ = 1;
+    SectorTurnstile *turn_ = nullptr;
+    long laps_ = 0;       // completed passes over the elevations (the global sequence number keeps growing)
     long max_sectors_ = -1, done_ = 0;
+    double seconds_ = 0;
     bool with_elevation_ = true;
     int status_ = 0;
+    std::string unicast_;
     Source source_;
+    std::function<void()> on_ready_;
     Sink sink_;
     std::unique_ptr<udpbroadcast::udpserver> server_;
     std::vector<std::unique_ptr<udpbroadcast::udpclient>> clients_;

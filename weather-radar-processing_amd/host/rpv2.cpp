@@ -1,64 +1,152 @@
 // rpv2.cpp -- entry point with the reference's name (Makefile:4 builds `rpv2`; main.cpp:3-16 is
 // the class-based variant).  usage:
-//   rpv2 [num_streams] [--in udp:PORT | file:PATH] [--out udp:PORT_ZDB,PORT_ZDR | file:PATH | none]
-//        [--sectors N] [--device D] [--no-elevation]
+//   rpv2 [num_streams] [--in udp:PORT | file:PATH | synthetic] [--out udp:PORT_ZDB,PORT_ZDR[@IPV4] | file:PATH | none]
+//        [--sectors N] [--device D | --devices D0,D1,...] [--no-elevation] [--scan SECTORS,ELEVATIONS]
 // Defaults reproduce main.cpp:10-15: 143 sectors x 9 elevations of 1024 x 512, UDP 19001 in,
-// 19002 / 19003 out.  file: input is a concatenation of wire-format sectors (12 bytes/sample),
+// 19002 / 19003 out (broadcast, as the reference; @IPV4 sends the products to one host instead).  file: input is a concatenation of wire-format sectors (12 bytes/sample),
 // file: output a concatenation of frames, Zdb then Zdr per sector.
+//
+// --devices: ONE host thread and ONE engine handle per listed GPU (a device may be listed twice to
+// rehearse on a smaller box); sector s of every elevation goes to GPU number s mod G of the list; the
+// threads take turns on the one source in acquisition order (SectorTurnstile) and run everything behind
+// the read -- pinned H2D on the GPU's slot cascade, decode, kernels, D2H, egress -- in parallel.  No
+// collective: sectors are independent.  With more than one GPU the frames of different
+// GPUs interleave on the output (each frame names its sector and elevation).
+// --in synthetic: the pinned slots keep whatever they hold (zeros at start): transport + GPU pipeline
+// rate without a real source.  The run's wall-clock rate is printed on stderr.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <memory>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "radar_processor.h"
 
 int main(int argc, char **argv)
 {
-    int num_streams = 2, device = 0;
+    int num_streams = 2;
     long sectors = -1;
     bool with_elev = true, with_elev_set = false;
+    int scan_sectors = 143, scan_elevations = 9;
+    std::vector<int> devices{0};
     std::string in = "udp:19001", out = "udp:19002,19003";
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--in" && i + 1 < argc) in = argv[++i];
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else if (a == "--sectors" && i + 1 < argc) sectors = atol(argv[++i]);
-        else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
-        else if (a == "--no-elevation") { with_elev = false; with_elev_set = true; }
+        else if (a == "--device" && i + 1 < argc) devices = {atoi(argv[++i])};
+        else if (a == "--devices" && i + 1 < argc) {
+            devices.clear();
+            for (char *tok = strtok(argv[++i], ","); tok; tok = strtok(nullptr, ",")) devices.push_back(atoi(tok));
+            if (devices.empty()) devices = {0};
+        } else if (a == "--scan" && i + 1 < argc) {
+            if (sscanf(argv[++i], "%d,%d", &scan_sectors, &scan_elevations) != 2 || scan_sectors < 1 || scan_elevations < 1) {
+                fprintf(stderr, "--scan SECTORS,ELEVATIONS\n");
+                return 2;
+            }
+        } else if (a == "--no-elevation") { with_elev = false; with_elev_set = true; }
         else if (a[0] != '-') { num_streams = atoi(a.c_str()); if (num_streams < 1) num_streams = 1; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    RadarProcessor proc(143, 1024, 512, 9, num_streams);
-    proc.set_device(device);
-    proc.set_max_sectors(sectors);
+    const int G = (int)devices.size();
+    std::vector<std::unique_ptr<RadarProcessor>> procs;
+    SectorTurnstile turn;
+    for (int g = 0; g < G; g++) {
+        procs.emplace_back(new RadarProcessor(scan_sectors, 1024, 512, scan_elevations, num_streams));
+        procs[g]->set_device(devices[g]);
+        procs[g]->set_max_sectors(sectors);
+        if (G > 1) procs[g]->set_shard(g, G, &turn);
+    }
     FILE *fin = nullptr, *fout = nullptr;
+    std::unique_ptr<udpbroadcast::udpserver> server;
+    std::vector<std::unique_ptr<udpbroadcast::udpclient>> clients;
     try {
-        if (in.rfind("udp:", 0) == 0 && out.rfind("udp:", 0) == 0) {
+        if (in.rfind("udp:", 0) == 0 && out.rfind("udp:", 0) == 0 && G == 1) {
             int ports[2] = {19002, 19003};
             sscanf(out.c_str() + 4, "%d,%d", &ports[0], &ports[1]);
-            proc.set_comms(atoi(in.c_str() + 4), ports, 2);
+            if (out.find('@') != std::string::npos) procs[0]->set_unicast(out.c_str() + out.find('@') + 1);
+            procs[0]->set_comms(atoi(in.c_str() + 4), ports, 2);
         } else {
+            RadarProcessor::Source src;
+            RadarProcessor::Sink sink;
             if (in.rfind("file:", 0) == 0) {
                 fin = fopen(in.c_str() + 5, "rb");
                 if (!fin) { perror("input"); return 2; }
-                proc.set_source([fin](char *buf, size_t bytes) { return fread(buf, 1, bytes, fin) == bytes; });
-            } else { fprintf(stderr, "mixing udp and file endpoints is not supported\n"); return 2; }
+                src = [fin](char *buf, size_t bytes) { return fread(buf, 1, bytes, fin) == bytes; };
+            } else if (in == "synthetic") {
+                src = [](char *, size_t) { return true; };
+            } else if (in.rfind("udp:", 0) == 0) {
+                server.reset(new udpbroadcast::udpserver(atoi(in.c_str() + 4)));
+                udpbroadcast::udpserver *sv = server.get();
+                src = [sv](char *buf, size_t bytes) {   // one datagram per range row (read_single.cc:145-148)
+                    const size_t row = (size_t)NUM_BYTES_PER_SAMPLE * 512;
+                    for (size_t off = 0; off < bytes; off += row)
+                        if (sv->recv(buf + off, row) != (int)row) return false;
+                    return true;
+                };
+                if (!with_elev_set) with_elev = false, with_elev_set = true;   // UDP products: 2-byte header
+            } else { fprintf(stderr, "unknown --in %s\n", in.c_str()); return 2; }
             if (out.rfind("file:", 0) == 0) {
                 fout = fopen(out.c_str() + 5, "wb");
                 if (!fout) { perror("output"); return 2; }
-                proc.set_sink([fout](int, int, int, const unsigned char *f, size_t n) { fwrite(f, 1, n, fout); });
+                sink = [fout](int, int, int, const unsigned char *f, size_t n) { fwrite(f, 1, n, fout); };
+            } else if (out.rfind("udp:", 0) == 0) {
+                int ports[2] = {19002, 19003};
+                sscanf(out.c_str() + 4, "%d,%d", &ports[0], &ports[1]);
+                const size_t at = out.find('@');
+                for (int k = 0; k < 2; k++)
+                    clients.emplace_back(at == std::string::npos ? new udpbroadcast::udpclient(ports[k])
+                                                                 : new udpbroadcast::udpclient(ports[k], out.c_str() + at + 1));
+                auto *cl = &clients;
+                sink = [cl](int which, int, int, const unsigned char *f, size_t n) { (*cl)[which]->send((const char *)f, n); };
+            } else if (out != "none") { fprintf(stderr, "unknown --out %s\n", out.c_str()); return 2; }
+            for (auto &p : procs) {
+                p->set_source(src);
+                if (sink) p->set_sink(sink);
             }
         }
     } catch (const char *msg) {
         fprintf(stderr, "socket: %s\n", msg);
         return 3;
     }
-    if (with_elev_set) proc.set_frame_with_elevation(with_elev);
-    const int rc = proc.start();
+    if (with_elev_set) for (auto &p : procs) p->set_frame_with_elevation(with_elev);
+    procs[0]->set_on_ready([] { fprintf(stderr, "rpv2: ready\n"); fflush(stderr); });
+
+    std::vector<int> rcs(G, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (G == 1) {
+        rcs[0] = procs[0]->start();
+    } else {
+        std::vector<std::thread> threads;
+        for (int g = 0; g < G; g++)
+            threads.emplace_back([&, g] {
+                try { rcs[g] = procs[g]->start(); } catch (const char *msg) { fprintf(stderr, "socket: %s\n", msg); rcs[g] = 3; }
+                if (rcs[g]) {   // a GPU that failed must not leave the others waiting for its turn
+                    std::lock_guard<std::mutex> lk(turn.mu);
+                    turn.ended = true;
+                    turn.cv.notify_all();
+                }
+            });
+        for (auto &t : threads) t.join();
+    }
+    (void)t0;
+    double dt = 1e-9;   // the slowest GPU's processing time (engine set-up excluded)
+    for (auto &p : procs) dt = p->processing_seconds() > dt ? p->processing_seconds() : dt;
     if (fin) fclose(fin);
     if (fout) fclose(fout);
-    if (rc) fprintf(stderr, "rpv2: %s\n", proc.last_error());
-    else fprintf(stderr, "rpv2: %ld sectors processed\n", proc.sectors_done());
-    return rc ? 1 : 0;
+    long total = 0;
+    int rc = 0;
+    for (int g = 0; g < G; g++) {
+        total += procs[g]->sectors_done();
+        if (rcs[g]) { fprintf(stderr, "rpv2: GPU %d: %s\n", devices[g], procs[g]->last_error()); rc = 1; }
+        else if (G > 1) fprintf(stderr, "rpv2: GPU %d (shard %d of %d): %ld sectors\n", devices[g], g, G, procs[g]->sectors_done());
+    }
+    if (!rc) fprintf(stderr, "rpv2: %ld sectors processed in %.3f s (%.0f sectors/s end to end, %d GPU thread%s, %d slots each)\n", total,
+                     dt, total / dt, G, G > 1 ? "s" : "", num_streams);
+    return rc;
 }

@@ -1,6 +1,7 @@
 // udpbroadcast.cpp -- see udpbroadcast.h.
 #include "udpbroadcast.h"
 
+#include <arpa/inet.h>
 #include <string.h>
 #include <sys/socket.h>
 #include <unistd.h>
@@ -37,6 +38,11 @@ udpclient::udpclient(int port) : to_(detail::DatagramSocket::address(INADDR_BROA
     ::setsockopt(sock_.fd(), SOL_SOCKET, SO_BROADCAST, &enable, sizeof enable);
 }
 
+udpclient::udpclient(int port, const char *ipv4) : to_(detail::DatagramSocket::address(INADDR_BROADCAST, port))
+{
+    if (!ipv4 || ::inet_pton(AF_INET, ipv4, &to_.sin_addr) != 1) throw "error address";
+}
+
 udpclient::~udpclient() {}
 
 int udpclient::send(const char *message, size_t length)
@@ -47,6 +53,9 @@ int udpclient::send(const char *message, size_t length)
 udpserver::udpserver(int port)
 {
     memset(&from_, 0, sizeof from_);
+    // a sector arrives as a burst of m datagrams (6 MiB): ask for as much kernel buffer as the host grants
+    const int want = 16 << 20;
+    ::setsockopt(sock_.fd(), SOL_SOCKET, SO_RCVBUF, &want, sizeof want);
     const sockaddr_in any = detail::DatagramSocket::address(INADDR_ANY, port);
     if (::bind(sock_.fd(), reinterpret_cast<const sockaddr *>(&any), sizeof any) != 0) throw "error bind";
 }

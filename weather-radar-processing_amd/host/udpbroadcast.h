@@ -31,6 +31,9 @@ class DatagramSocket {
 class udpclient {
   public:
     udpclient(int port);
+    // extension (not in the reference): unicast to a dotted-quad IPv4 address, e.g. "127.0.0.1" on a
+    // host without a broadcast route; throws "error address" if it does not parse
+    udpclient(int port, const char *ipv4);
     ~udpclient();
     int send(const char *message, size_t length);   // bytes sent or -1
   private:
