@@ -56,12 +56,11 @@ def host_cpus():
     return len(usable), max(len(cores), 1), model
 
 
-def cpu_baseline_child(threads, budget_s):
+def cpu_baseline_child(threads, budget_s, m=1024, n=512):
     """Runs in a FRESH process whose OMP_NUM_THREADS was set before anything was imported."""
     import numpy as np
     from oracle import oracle as O
     O.build()
-    m, n = 1024, 512
     iq = O.synthetic_sector(0, m, n)
     coef = O.hamming_coef(m, n, np.float32)
     O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)            # warm-up
@@ -76,13 +75,13 @@ def cpu_baseline_child(threads, budget_s):
     print(json.dumps({"sectors": cnt, "seconds": dt}))
 
 
-def cpu_baseline():
+def cpu_baseline(m=1024, n=512):
     logical, physical, model = host_cpus()
     threads = min(logical, 16)          # 16 = the CPU share of a one-GPU box; stated in `sample`
 
     def run(t, budget):
         env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PROC_BIND="close")
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(t), str(budget)],
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(t), str(budget), str(m), str(n)],
                              env=env, capture_output=True, text=True, timeout=300)
         r = json.loads(out.stdout.strip().splitlines()[-1])
         return r["sectors"] / r["seconds"], r
@@ -96,8 +95,8 @@ def cpu_baseline():
 
 
 def main():
-    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-child":
-        return cpu_baseline_child(int(sys.argv[2]), float(sys.argv[3]))
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_child(int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # a step is ~1 ms: the defaults keep the GPU busy for ~0.3 s so that its clocks have settled
@@ -106,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--sectors", type=int, default=360, help="sectors per step per GPU (one elevation sweep)")
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("WRP_MAX_BATCH", "0")))
+    ap.add_argument("--shape", choices=["A", "B"], default="A",
+                    help="A: the 00iq.altb shape 1024 x 512 (BASELINE metric); B: configs[4]'s 2048 range gates x 128 pulses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -132,10 +133,10 @@ def main():
         # no collective and RCCL is never initialised (north_star)
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    m, n, C = 1024, 512, 2
+    m, n, C = (1024, 512, 2) if args.shape == "A" else (2048, 128, 2)
     S = args.sectors
     SLOTS = 4
-    cfg = dict(n_slots=SLOTS, n_sectors=S, n_elevations=1)
+    cfg = dict(n_slots=SLOTS, n_sectors=S, n_elevations=1, m=m, n=n)
     if args.max_batch > 0:
         cfg["max_batch"] = args.max_batch
     if os.environ.get("WRP_FLAGS"):          # A/B measurements only (e.g. 0x800 = two kernels)
@@ -195,18 +196,21 @@ def main():
     achieved = algo / t_sector / 1e9
     c2 = wrp_amd.WrpConfig()
     eng.lib.wrp_get_config(eng.handle, c2)
-    fused = (c2.flags & wrp_amd.FLAG_TWO_KERNELS) == 0 and S >= wrp_amd.FUSED_MIN_SECTORS
+    fused = args.shape == "A" and (c2.flags & wrp_amd.FLAG_TWO_KERNELS) == 0 and S >= wrp_amd.FUSED_MIN_SECTORS
     per_launch = S if fused else min(S, c2.max_batch)
     launches = 1 if fused else -(-S // c2.max_batch)
     kernel = ("fused_chain_1024x512 (one persistent launch per sweep: tile + row workgroups, intermediate in the XCDs' L2)"
-              if fused else "range_pass_1024_persistent + doppler_pass_512 (one launch pair per chunk)")
+              if fused else "range_pass_1024_persistent + doppler_pass_512 (one launch pair per chunk)" if args.shape == "A"
+              else "range_pass_2048 + doppler_pass_128 (one launch pair per chunk)")
     # HBM traffic per launch from the rocprofv3 PMC run of the SAME library sources (FETCH_SIZE / WRITE_SIZE in
     # separate passes, gfx950 correction applied; tools/profile_pmc.sh -> tools/make_traffic.py).  The file
     # records a fingerprint of csrc/, include/ and the compiler flags: anything else reads null.
     traffic, traffic_note = None, "no traffic file for this build"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))
-        if tj.get("fingerprint") != wrp_amd.source_fingerprint():
+        if args.shape != "A":
+            traffic_note = "no PMC run for this shape"
+        elif tj.get("fingerprint") != wrp_amd.source_fingerprint():
             traffic_note = "profiles/%s/traffic.json was measured on other sources (fingerprint differs)" % PROFILE_ROUND
         elif tj.get("sectors_per_launch") != per_launch or tj.get("fused") != fused:
             traffic_note = "profiles/%s/traffic.json was measured on another configuration" % PROFILE_ROUND
@@ -230,7 +234,7 @@ def main():
     # the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB, 4 slots cascading, all ranks at once.
     end_to_end = None
     if not args.no_end_to_end:
-        w = np.zeros((m * n, 6), dtype=">i2")
+        w = np.zeros((m * n, 6), dtype=">i2")      # (rows of 12 n bytes: the wire format is shape-agnostic)
         for c in range(2):
             w[:, 2 * c] = pool[0][c].real.ravel()
             w[:, 2 * c + 1] = pool[0][c].imag.ravel()
@@ -253,7 +257,7 @@ def main():
         want = O.sector(pool[0][0], pool[0][1], dtype=np.float64)
         e_ok = bool(np.max(np.abs(eng.result(S - 1, 0)[1:] - want[1:])) < 1e-3)
         end_to_end = {"value": round(world * S / dt, 1), "unit": "sectors/s", "slots": SLOTS, "sectors_per_gpu": S,
-                      "ingest": "wire format, 12 B/sample big-endian int16 (6 MiB/sector), decoded on the GPU",
+                      "ingest": f"wire format, 12 B/sample big-endian int16 ({m * n * 12 / 2**20:g} MiB/sector), decoded on the GPU",
                       "h2d_GBps_per_gpu": round(S * m * n * 12 / dt / 1e9, 1), "spot_check_vs_oracle": e_ok,
                       "includes": "pinned H2D + decode + range/Doppler kernels + D2H per sector; host refill of the pinned "
                                   "slots not included"}
@@ -266,8 +270,10 @@ def main():
         "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"00iq.altb shape (C=2, m=1024, n=512, fp32 complex), {S}-sector elevation "
-                               f"sweep per GPU per step, device-resident", "sectors_per_step_per_gpu": S,
+        "config": {"workload": (f"00iq.altb shape (C=2, m=1024, n=512, fp32 complex), {S}-sector elevation "
+                                f"sweep per GPU per step, device-resident") if args.shape == "A" else
+                               (f"shape B = BASELINE configs[4] (C=2, m=2048 range gates, n=128 pulses, fp32 complex), {S} sectors "
+                                f"per GPU per step, device-resident"), "sectors_per_step_per_gpu": S,
                    "parallelism": f"sector-sharded x{world}, no collective (gloo barrier + MAX only)",
                    "launch": "fused" if fused else "two kernels"},
         "achieved_hbm_GBps": round(world * achieved, 1),
@@ -277,7 +283,7 @@ def main():
     if end_to_end is not None:
         line["end_to_end"] = end_to_end
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline()
+        line["cpu_baseline"] = cpu_baseline(m, n)
     eng.close()
     if dist is not None:
         dist.barrier()

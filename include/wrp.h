@@ -81,6 +81,9 @@ typedef struct {
  * one-tile-per-workgroup form instead (same arithmetic, bit-identical results; A/B only). */
 #define WRP_FLAG_ONE_TILE_PER_BLOCK 0x400
 
+/* m = 2048, n = 128 (BASELINE configs[4]) has tuned kernels of its own (csrc/wrp_shape_b.h); this flag runs the
+ * shape-generic radix-2 kernels instead (every other shape always does): parity tests and A/B */
+#define WRP_FLAG_GENERIC_KERNELS 0x8000
 /* test hook: the fused launch is issued with half its workgroups, so that it must report (wrp_check)
  * that its teams are incomplete and the handle must fall back to the two kernels */
 #define WRP_FLAG_DEBUG_FUSED_UNDERSIZED 0x4000

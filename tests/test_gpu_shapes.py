@@ -46,3 +46,23 @@ def test_unsupported_shapes_are_refused():
     for m, n in ((4096, 512), (1024, 2048), (32, 32), (1024, 16), (1000, 512)):
         cfg = wrp_amd.binding.default_config(m=m, n=n)
         assert lib.wrp_create(C.byref(cfg), 0, C.byref(h)) == -4, (m, n)
+
+
+def test_shape_b_tuned_kernels_against_generic_and_oracle(oracle):
+    """configs[4]'s 2048 x 128 has tuned kernels (csrc/wrp_shape_b.h: 16 x 16 x 8 range FFT through a grouped LDS
+    image, 16 lanes per Doppler row); the shape-generic radix-2 kernels produce its stage dumps.  Final outputs
+    of both against the fp64 oracle and against each other, for a batch that keeps the walking grid busy for
+    several tiles per workgroup and for distinct sectors (a tile / gate mix-up would show)."""
+    import wrp_amd
+    m, n = 2048, 128
+    batch = np.stack([oracle.synthetic_sector(s, m, n) * np.float32(1 + 0.5 * (s % 3)) for s in range(40)])
+    with wrp_amd.Engine(device=0, m=m, n=n, n_slots=1) as et, \
+            wrp_amd.Engine(device=0, m=m, n=n, n_slots=1, flags=wrp_amd.FLAG_GENERIC_KERNELS) as eg:
+        a, b = et.process_host(batch), eg.process_host(batch)
+    assert not np.array_equal(a, b)                                  # really two implementations
+    assert np.all(np.isneginf(a[:, 0, 0])) and np.all(np.isneginf(b[:, 0, 0]))
+    assert np.max(np.abs(a[:, 1:, 0] - b[:, 1:, 0])) < 2e-5 and np.max(np.abs(a[:, :, 1] - b[:, :, 1])) < 2e-5      # dB
+    for s in (0, 17, 39):
+        want = oracle.sector(batch[s][0], batch[s][1], dtype=np.float64)
+        assert np.max(np.abs(a[s, 1:, 0] - want[1:, 0]) / np.abs(want[1:, 0])) < 1e-5
+        assert np.max(np.abs(a[s, :, 1] - want[:, 1])) < 2e-5

@@ -26,7 +26,7 @@ class WrpConfig(C.Structure):
     ]
 
 
-FLAG_FUSED, FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_DEBUG_FUSED_UNDERSIZED = 0x100, 0x400, 0x800, 0x4000
+FLAG_FUSED, FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_DEBUG_FUSED_UNDERSIZED, FLAG_GENERIC_KERNELS = 0x100, 0x400, 0x800, 0x4000, 0x8000
 FUSED_MIN_SECTORS = 8
 
 STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7}

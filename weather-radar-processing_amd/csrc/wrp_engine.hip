@@ -16,6 +16,7 @@
 #include "wrp_kernels.h"
 #include "wrp_generic.h"
 #include "wrp_fused.h"
+#include "wrp_shape_b.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 
@@ -48,6 +49,7 @@ struct wrp_engine {
     wrp::MaTaps taps;
     int taps_pad = 7;
     bool tuned = true;        // m = 1024, n = 512: tuned kernels; otherwise wrp_generic.h
+    bool tuned_b = false;     // m = 2048, n = 128 (BASELINE configs[4]): wrp_shape_b.h; its stage dumps come from wrp_generic.h
     bool persist = false;     // range pass as a fixed grid walking the tiles with prefetch
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
     // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors
@@ -135,6 +137,13 @@ void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mi
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
+    if (h->tuned_b && !dump) {
+        const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
+        const int total = n_sectors * 2 * (wrp::RB_N / 16), grid = std::min(total, h->n_cus);
+        hipLaunchKernelGGL(wrp::range_pass_2048, dim3(grid), dim3(wrp::RangeTileB::THREADS), wrp::RangeTileB::LDS_BYTES, st, d_iq,
+                           d_mid, rc, h->cfg.channels, total);
+        return;
+    }
     if (!h->tuned) {
         const wrp_config &c = h->cfg;
         const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
@@ -189,6 +198,17 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
+    if (h->tuned_b && !dump) {
+        const wrp_config &c = h->cfg;
+        const dim3 grid(c.m / 2 / (wrp::DB_WAVES * 2), n_sectors), block(wrp::DB_WAVES * 64);
+        if (h->taps_pad == 7)
+            hipLaunchKernelGGL(wrp::doppler_pass_128<7>, grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps,
+                               c.k_range_resolution, c.k_calibration);
+        else
+            hipLaunchKernelGGL(wrp::doppler_pass_128<9>, grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps,
+                               c.k_range_resolution, c.k_calibration);
+        return;
+    }
     if (!h->tuned) {
         const wrp_config &c = h->cfg;
         const dim3 grid(c.m / 2, n_sectors), block(64);
@@ -306,6 +326,9 @@ int create_impl(wrp_engine *h)
     // up to 144 KiB of dynamic LDS for the range pass
     h->range_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // default chosen below
     h->tuned = shape_tuned(c.m, c.n);
+    h->tuned_b = c.m == wrp::RB_M && c.n == wrp::RB_N && (c.flags & WRP_FLAG_GENERIC_KERNELS) == 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_2048),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
     // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
     h->fused = h->tuned && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
@@ -411,7 +434,7 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED)) != 0 ||
+        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED | WRP_FLAG_GENERIC_KERNELS)) != 0 ||
         ((cfg->flags & WRP_FLAG_FUSED) && (cfg->flags & WRP_FLAG_TWO_KERNELS)) || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
