@@ -41,7 +41,14 @@ __global__ __launch_bounds__(512) void k_rewrite(float *buf, const float *in, fl
             // cache policy of the rewritten buffer's stores: 0 plain, 1 nt, 2 sc0
             if (st_sel == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 0);
             else if (st_sel == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 2);
-            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 1);
+            else if (st_sel == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 1);
+            else {   // 3: the same bytes as two 8-byte stores per lane, 16 lanes per 128-byte line (the fused launch's tile stores)
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const int l = tid & 63, base = off - l * 16;          // this wave-instruction's 1 KiB
+                v2u d = {(unsigned)r, (unsigned)off};
+                __builtin_amdgcn_raw_buffer_store_b64(d, rb, base + l * 8, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rb, base + 512 + l * 8, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -15,10 +15,9 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
 print(f"{sys.argv[2]:28s} {sys.argv[3]} = {tot / 1024:.1f} MiB")
 PY
 }
-for st in 0 1 2; do
-  run w_m7_c65536_st$st WRITE_SIZE 7 50 65536 131072 1 $st
+for st in 0 3; do
+  run f_m4_c32768_st$st FETCH_SIZE 4 50 32768 131072 1 $st
+  run w_m4_c32768_st$st WRITE_SIZE 4 50 32768 131072 1 $st
   run f_m7_c65536_st$st FETCH_SIZE 7 50 65536 131072 1 $st
+  run w_m7_c65536_st$st WRITE_SIZE 7 50 65536 131072 1 $st
 done
-# half the stream per repetition (what a longer-lived buffer would see per generation)
-run w_m7_c65536_s64k WRITE_SIZE 7 50 65536 65536 1 0
-run w_m7_c65536_s32k WRITE_SIZE 7 50 65536 32768 1 0

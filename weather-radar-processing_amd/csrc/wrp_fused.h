@@ -314,21 +314,12 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
         }
 }
 
-template <int TAPS, bool STAMPS>
-__global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
-    const float2 *__restrict__ iq,   // [S][C][1024][512]
-    float *__restrict__ out,         // [S][512][2]
-    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[512][512]
-    FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
-    float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
+// Who am I: XCD, kind (first / second workgroup to arrive on this CU), rank inside the team; the grid meets
+// once (census), afterwards the teams never talk to each other.  Every thread of the workgroup calls.
+struct FusedSeat { int ok, xcc, kind, rank, teams, trank; };
+__device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
 {
-    typedef FusedTile T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lds_word *s_ctl = (lds_word *)(smem + T::OFF_CTL);
-    const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
-    const int n = DP_N, gates = RP_M / 2;
-
-    // ---- who am I: XCD, kind (first / second workgroup on this CU), rank inside the team --------
+    const int tid = threadIdx.x;
     if (tid == 0) {
         const unsigned x = xcc_id();
         const unsigned a = atomicAdd(&ctl->cu_arrivals[x][hw_cu_key()], 1u);
@@ -359,11 +350,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         s_ctl[5] = trank;
     }
     __syncthreads();
-    if (!s_ctl[0]) return;
-    // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
-    const int xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]), kind = __builtin_amdgcn_readfirstlane(s_ctl[2]);
-    const int rank = __builtin_amdgcn_readfirstlane(s_ctl[3]);
-    const int teams = __builtin_amdgcn_readfirstlane(s_ctl[4]), trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
+    FusedSeat r;   // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
+    r.ok = __builtin_amdgcn_readfirstlane(s_ctl[0]);
+    r.xcc = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+    r.kind = __builtin_amdgcn_readfirstlane(s_ctl[2]);
+    r.rank = __builtin_amdgcn_readfirstlane(s_ctl[3]);
+    r.teams = __builtin_amdgcn_readfirstlane(s_ctl[4]);
+    r.trank = __builtin_amdgcn_readfirstlane(s_ctl[5]);
+    return r;
+}
+
+template <int TAPS, bool STAMPS>
+__global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
+    const float2 *__restrict__ iq,   // [S][C][1024][512]
+    float *__restrict__ out,         // [S][512][2]
+    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[512][512]
+    FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
+    float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
+{
+    typedef FusedTile T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_word *s_ctl = (lds_word *)(smem + T::OFF_CTL);
+    const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
+    const int n = DP_N, gates = RP_M / 2;
+
+    const FusedSeat seat = fused_join(ctl, s_ctl);
+    if (!seat.ok) return;
+    const int xcc = seat.xcc, kind = seat.kind, rank = seat.rank, teams = seat.teams, trank = seat.trank;
     if (rank >= FUSED_MEMBERS) return;   // surplus workgroups own nothing
     const int tasks = 2 * ((n_sectors - trank + teams - 1) / teams);   // channel-tasks of this team
     float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
