@@ -46,6 +46,7 @@ struct wrp_engine {
     float *d_wd = nullptr;    // [n]
     float2 *d_tw_m = nullptr; // [m]  exp(-2 pi i k / m)
     float2 *d_tw_n = nullptr; // [n]  exp(+2 pi i k / n)
+    float2 *d_tw_n_arr = nullptr;   // n = 512: the same values in the per-lane arrangement of doppler_twiddles_to_lds
     wrp::MaTaps taps;
     int taps_pad = 7;
     bool tuned = true;        // m = 1024, n = 512: tuned kernels; otherwise wrp_generic.h
@@ -189,7 +190,7 @@ void launch_doppler_t(wrp_engine *h, const float2 *d_mid, int n_sectors, float *
 {
     const wrp_config &c = h->cfg;
     const dim3 grid(c.m / 2 / wrp::DP_WAVES, n_sectors), block(wrp::DP_WAVES * 64);
-    hipLaunchKernelGGL((wrp::doppler_pass_512<DUMP, TAPS>), grid, block, 0, st, d_mid, d_out, h->d_tw_n,
+    hipLaunchKernelGGL((wrp::doppler_pass_512<DUMP, TAPS>), grid, block, 0, st, d_mid, d_out, h->d_tw_n_arr,
                        c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, d);
 }
 
@@ -242,7 +243,7 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
 #define WRP_FUSED(TAPS, STAMPS)                                                                                       \
     hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
-                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n, n_sectors, \
+                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n_arr, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
     if (d_stamps) {
         if (h->taps_pad == 7) WRP_FUSED(7, true); else WRP_FUSED(9, true);
@@ -315,6 +316,7 @@ int destroy_impl(wrp_engine *h)
     if (h->d_wd) (void)hipFree(h->d_wd);
     if (h->d_tw_m) (void)hipFree(h->d_tw_m);
     if (h->d_tw_n) (void)hipFree(h->d_tw_n);
+    if (h->d_tw_n_arr) (void)hipFree(h->d_tw_n_arr);
     delete h;
     return WRP_OK;
 }
@@ -381,6 +383,12 @@ int create_impl(wrp_engine *h)
     HIP_TRY(h, hipMemcpy(h->d_wd, wd.data(), sizeof(float) * c.n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw_m, twm.data(), sizeof(float2) * c.m, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_tw_n, twn.data(), sizeof(float2) * c.n, hipMemcpyHostToDevice));
+    if (h->tuned) {
+        std::vector<float2> arr(wrp::DP_TW_ELEMS);
+        for (int e = 0; e < wrp::DP_TW_ELEMS; e++) arr[e] = twn[wrp::doppler_twiddle_index(e)];
+        HIP_TRY(h, hipMalloc(&h->d_tw_n_arr, sizeof(float2) * arr.size()));
+        HIP_TRY(h, hipMemcpy(h->d_tw_n_arr, arr.data(), sizeof(float2) * arr.size(), hipMemcpyHostToDevice));
+    }
 
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(h, hipEventCreate(&h->ev0));

@@ -82,14 +82,18 @@ struct FusedTile {
     static constexpr int IMG_BYTES = BLOCKS * BLK_BYTES;         // 73728
     static constexpr int OFF_WR = IMG_BYTES;                     // float wr_c[1024]
     static constexpr int OFF_CTL = OFF_WR + RP_M * 4;            // 77824: control words, both kinds
-    static constexpr int OFF_STAMPS = OFF_CTL + 64;              // diagnostics build: [16 tasks][9] 64-bit stamps
-    static constexpr int LDS_BYTES = OFF_STAMPS + FUSED_STAMP_TASKS * FUSED_STAMPS * 8;   // 79040 -> exactly two workgroups per CU
+    static constexpr int OFF_TW2 = OFF_CTL + 64;                 // float2 [8][8]: W_64^{p1 k2}, the stage-2 twiddles
+    static constexpr int OFF_STAMPS = OFF_TW2 + 512;             // diagnostics build: [16 tasks][9] 64-bit stamps
+    static constexpr int LDS_BYTES = OFF_STAMPS + FUSED_STAMP_TASKS * FUSED_STAMPS * 8;   // 79552 -> exactly two workgroups per CU
     // row workgroup: 8 wave buffers, then the Doppler twiddles
     static constexpr int OFF_TWN = 8 * DP_ELEMS * 8;             // 36864
-    static_assert(OFF_TWN + DP_N * 8 <= OFF_CTL, "row workgroup layout fits");
+    static_assert(OFF_TWN + DP_TW_ELEMS * 8 <= OFF_CTL, "row workgroup layout fits");
     static_assert(2 * LDS_BYTES <= 160 * 1024 && 3 * LDS_BYTES > 160 * 1024, "exactly two workgroups per CU");
     static __device__ __forceinline__ int addr(int pos, int cp) { return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + cp * 16; }
-    static __device__ __forceinline__ int tw_addr(int e) { return (e >> 4) * BLK_BYTES + 8 * ROW_BYTES + (e & 15) * 8; }
+    // Stage-1 twiddles ARRANGED per position: the pad behind block p0 holds W_1024^{p0 k1}, k1 < 16 -- a lane reads
+    // its fifteen twiddles at `pad of p0 + 8 k1` (immediate offsets) instead of computing fifteen table addresses.
+    static __device__ __forceinline__ int tw1_addr(int p0, int k1) { return p0 * BLK_BYTES + 8 * ROW_BYTES + k1 * 8; }
+    static __device__ __forceinline__ int tw2_addr(int p1, int k2) { return OFF_TW2 + (p1 * 8 + k2) * 8; }
 };
 
 __device__ __forceinline__ unsigned xcc_id()
@@ -201,15 +205,16 @@ __device__ __forceinline__ void fused_stage1_column(unsigned char *smem, cf (&a)
 {
     typedef FusedTile T;
     fft16<-1>(a);
+    const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
+        const cf t = *reinterpret_cast<const float2 *>(tw1 + k1 * 8);
         *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t);
     }
 #pragma unroll
     for (int k1 = 8; k1 < 16; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
+        const cf t = *reinterpret_cast<const float2 *>(tw1 + k1 * 8);
         g[k1 - 8] = cmul(a[k1], t);
     }
 }
@@ -219,6 +224,7 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // per-lane LDS addresses are recomputed per tile, not hoisted + spilled
+    tid &= FUSED_THREADS - 1;       // (the compiler knows the range again: address arithmetic folds)
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
@@ -238,6 +244,7 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
 #pragma unroll
@@ -259,6 +266,7 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;   // position w*64 of this lane's column
 #pragma unroll
@@ -271,10 +279,9 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
         *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
 #pragma unroll
         for (int k2 = 1; k2 < 8; k2++) {
-            const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((16 * p1 * k2) & (RP_M - 1)));
+            const cf t = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
             *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t);
         }
-        __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved they need twice the registers
     }
     wave_lds_fence();
 }
@@ -283,6 +290,7 @@ __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
 #pragma unroll
@@ -294,13 +302,13 @@ __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
         fft8<-1>(a);
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
     const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
@@ -418,9 +426,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         fused_tile_load<2>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
         fused_tile_load<3>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
         for (int e = tid; e < RP_M; e += FUSED_THREADS) {                 // ... tables while they fly
-            *reinterpret_cast<float2 *>(smem + T::tw_addr(e)) = rc.tw[e];
+            const int p0 = e >> 4, k1 = e & 15;
+            *reinterpret_cast<float2 *>(smem + T::tw1_addr(p0, k1)) = rc.tw[(p0 * k1) & (RP_M - 1)];
             reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
         }
+        if (tid < 64) *reinterpret_cast<float2 *>(smem + T::tw2_addr(tid >> 3, tid & 7)) = rc.tw[(16 * (tid >> 3) * (tid & 7)) & (RP_M - 1)];
         __syncthreads();
         // The tile waves are the critical path of a task and the row waves of this CU have slack: when
         // both want the SIMD, the tile wave goes first.
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         // (counted in LDS) counts the member as loaded.
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
-        for (int e = tid; e < DP_N; e += FUSED_THREADS) s_twn[e] = tw_n[e];
+        doppler_twiddles_to_lds(s_twn, tw_n, tid, FUSED_THREADS);
         if (tid < 2) s_ctl[12 + tid] = 0;
         __syncthreads();
         const DumpPtrs nodump{};

@@ -417,14 +417,33 @@ __device__ __forceinline__ void doppler_load_row(const float2 *row /* wave-unifo
     for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX>(rs, l * 8, 64 * r * 8);
 }
 
+// The Doppler twiddles in LDS, ARRANGED per lane so that every read is `lane base + immediate offset` instead of
+// an index computation per twiddle, and lane-contiguous so that a wave's b64 read has no bank conflict:
+// [8 k][64 lanes] W^{l k} (stage 1), then [8 k][8 p] W^{8 p k} (stage 2), W = exp(+2 pi i / 512).
+// The engine keeps the table in this arrangement in device memory (wrp_engine.hip: arranged_doppler_twiddles), so
+// filling LDS is a plain coalesced copy.
+constexpr int DP_TW_ELEMS = 64 * 8 + 8 * 8;
+__host__ __device__ inline int doppler_twiddle_index(int e)   // arranged entry e -> index into exp(+2 pi i k / 512)
+{
+    if (e < 512) return ((e & 63) * (e >> 6)) & (DP_N - 1);    // stage 1: k = e >> 6, lane = e & 63
+    e -= 512;
+    return (8 * (e & 7) * (e >> 3)) & (DP_N - 1);              // stage 2: k = e >> 3, p = e & 7
+}
+__device__ __forceinline__ void doppler_twiddles_to_lds(float2 *s_tw, const float2 *tw_arranged /* [DP_TW_ELEMS] global */, int tid,
+                                                        int threads)
+{
+    for (int e = tid; e < DP_TW_ELEMS; e += threads) s_tw[e] = tw_arranged[e];
+}
+
 // a4..a8 for one row held in v (lane l: j = l + 64 r); returns S (the same value in every lane).
-// tw: LDS table exp(+2 pi i k / 512).
+// tw: the arranged LDS table of doppler_twiddles_to_lds.
 template <bool DUMP, int TAPS>
 __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const float2 *tw, const MaTaps &taps, int l,
                                              int gate, bool do_dump, const DumpPtrs &dump)
 {
     float *fbuf = reinterpret_cast<float *>(buf);
     asm volatile("" : "+v"(l));   // keep the per-lane LDS addresses inside the row (see range_stage12)
+    l &= 63;                      // ... but let the compiler know its range again: (c*64 + l) >> 4 folds only then
     // a4: mean over the row, subtract (rpv2.cu:434-439)
     float sr = 0.f, si = 0.f;
 #pragma unroll
@@ -438,8 +457,8 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
     cf t1[8], t2[8];                               // both twiddle sets in one batch of LDS reads
 #pragma unroll
     for (int k = 1; k < 8; k++) {
-        t1[k] = tw[(l * k) & (DP_N - 1)];
-        t2[k] = tw[(8 * (l & 7) * k) & (DP_N - 1)];
+        t1[k] = tw[k * 64 + l];
+        t2[k] = tw[512 + k * 8 + (l & 7)];
     }
     fft8<+1>(v);                                   // stage 1: lane l owns j = l + 64 r
     buf[dp_idx(l)] = v[0];
@@ -523,11 +542,11 @@ template <bool DUMP, int TAPS>
 __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
     const float2 *__restrict__ mid,  // [S][2][gates][512]
     float *__restrict__ out,         // [S][gates][2]
-    const float2 *__restrict__ tw,   // [512] exp(+2 pi i k / 512)
+    const float2 *__restrict__ tw,   // [DP_TW_ELEMS] exp(+2 pi i k / 512), arranged (doppler_twiddle_index)
     int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DP_WAVES][DP_ELEMS];
-    __shared__ __attribute__((aligned(16))) float2 s_tw[DP_N];
+    __shared__ __attribute__((aligned(16))) float2 s_tw[DP_TW_ELEMS];
     const int w = wave_id(), l = threadIdx.x & 63;
     const int gate = blockIdx.x * DP_WAVES + w;
     const int sec = blockIdx.y;
@@ -535,7 +554,7 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 #pragma unroll
     for (int ch = 0; ch < 2; ch++)
         doppler_load_row<AUX_NT>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
-    for (int e = threadIdx.x; e < DP_N; e += DP_WAVES * 64) s_tw[e] = tw[e];
+    doppler_twiddles_to_lds(s_tw, tw, threadIdx.x, DP_WAVES * 64);
     __syncthreads();
     float S[2];
 #pragma unroll
