@@ -90,9 +90,13 @@ struct FusedTile {
     static_assert(OFF_TWN + DP_TW_ELEMS * 8 <= OFF_CTL, "row workgroup layout fits");
     static_assert(2 * LDS_BYTES <= 160 * 1024 && 3 * LDS_BYTES > 160 * 1024, "exactly two workgroups per CU");
     static __device__ __forceinline__ int addr(int pos, int cp) { return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + cp * 16; }
-    // Stage-1 twiddles ARRANGED per position: the pad behind block p0 holds W_1024^{p0 k1}, k1 < 16 -- a lane reads
-    // its fifteen twiddles at `pad of p0 + 8 k1` (immediate offsets) instead of computing fifteen table addresses.
-    static __device__ __forceinline__ int tw1_addr(int p0, int k1) { return p0 * BLK_BYTES + 8 * ROW_BYTES + k1 * 8; }
+    // Stage-1 twiddles W_1024^{p0 k1} ARRANGED in the 64 pads so that a lane reads its fifteen at ONE base + immediate
+    // offsets, and the eight positions p0 = 8 w .. 8 w + 7 of a wave are 64 contiguous bytes (no bank conflict): pad
+    // 8 (p0 >> 3) + (k1 >> 1), byte 64 (k1 & 1) + 8 (p0 & 7).
+    static __device__ __forceinline__ int tw1_addr(int p0, int k1)
+    {
+        return ((p0 >> 3) * 8 + (k1 >> 1)) * BLK_BYTES + 8 * ROW_BYTES + (k1 & 1) * 64 + (p0 & 7) * 8;
+    }
     static __device__ __forceinline__ int tw2_addr(int p1, int k2) { return OFF_TW2 + (p1 * 8 + k2) * 8; }
 };
 
@@ -205,16 +209,16 @@ __device__ __forceinline__ void fused_stage1_column(unsigned char *smem, cf (&a)
 {
     typedef FusedTile T;
     fft16<-1>(a);
-    const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);
+    const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);   // k1 further on: a compile-time offset
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(tw1 + k1 * 8);
+        const cf t = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
         *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t);
     }
 #pragma unroll
     for (int k1 = 8; k1 < 16; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(tw1 + k1 * 8);
+        const cf t = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
         g[k1 - 8] = cmul(a[k1], t);
     }
 }
