@@ -85,12 +85,18 @@ int main(int argc, char **argv)
     const int stream = argc > 4 ? atoi(argv[4]) : 131072;    // 128 KiB per workgroup and repetition
     const int aux_sel = argc > 5 ? atoi(argv[5]) : 1;
     const int st_sel = argc > 6 ? atoi(argv[6]) : 0;
+    const int in_mem = argc > 7 ? atoi(argv[7]) : 0;         // memory of the streamed input: 0 hipMalloc, 1 uncached, 2 fine-grained
     float *buf, *in, *sink;
     CK(hipMalloc(&buf, (size_t)256 * chunk));
-    CK(hipMalloc(&in, (size_t)256 * stream * reps + 4096));
+    if (in_mem == 0) CK(hipMalloc(&in, (size_t)256 * stream * reps + 4096));
+    else CK(hipExtMallocWithFlags((void **)&in, (size_t)256 * stream * reps + 4096, in_mem == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
     CK(hipMalloc(&sink, 4096));
     CK(hipMemset(in, 1, (size_t)256 * stream * reps));
     CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
     switch (mode) {
     case 0: hipLaunchKernelGGL(k_rewrite<0>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
     case 1: hipLaunchKernelGGL(k_rewrite<1>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
@@ -100,7 +106,11 @@ int main(int argc, char **argv)
     case 5: hipLaunchKernelGGL(k_rewrite<5>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
     default: hipLaunchKernelGGL(k_rewrite<7>, dim3(256), dim3(512), 0, 0, buf, in, sink, chunk, reps, stream, aux_sel, st_sel); break;
     }
+    CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("in_mem %d: %.1f us per repetition\n", in_mem, ms * 1000 / reps);
     printf("mode %d reps %d chunk %d stream %d: stored per generation %.1f MiB, streamed per repetition %.1f MiB\n", mode, reps,
            chunk, stream, 256.0 * chunk / 1048576, (mode & 2) ? 256.0 * stream / 1048576 : 0.0);
     return 0;

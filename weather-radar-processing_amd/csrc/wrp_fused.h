@@ -69,6 +69,7 @@ struct FusedCtl {               // zeroed by hipMemsetAsync before every launch
     unsigned census[2][8];      // workgroups per kind (0 tile, 1 row) and XCC
     unsigned pad1[16];
     unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
+    unsigned cu_block[8][256][2];            // blockIdx + 1 of the first and the second workgroup to arrive there
     FusedLine stored[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: tile halves stored so far; polled by row member r only
     FusedLine loaded[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: row sets loaded so far; polled by tile member r only
 };
@@ -326,16 +327,29 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
         }
 }
 
-// Who am I: XCD, kind (first / second workgroup to arrive on this CU), rank inside the team; the grid meets
+// Who am I: XCD, kind (the older / the younger of the two workgroups on this CU), rank inside the team; the grid meets
 // once (census), afterwards the teams never talk to each other.  Every thread of the workgroup calls.
 struct FusedSeat { int ok, xcc, kind, rank, teams, trank; };
 __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
 {
     const int tid = threadIdx.x;
     if (tid == 0) {
-        const unsigned x = xcc_id();
-        const unsigned a = atomicAdd(&ctl->cu_arrivals[x][hw_cu_key()], 1u);
-        const unsigned kind = a & 1u;
+        const unsigned x = xcc_id(), key = hw_cu_key();
+        const unsigned a = atomicAdd(&ctl->cu_arrivals[x][key], 1u);
+        // The two workgroups of a CU meet: the OLDER one (lower blockIdx: dispatched first) is the tile workgroup.
+        // A SIMD issues from its oldest ready wave first, and the tile waves are the critical path of a task; where
+        // the younger workgroup had the tile role (it wins the race to the counter on ~3 % of the CUs), that member
+        // ran 10 % slower than the others for the whole launch (scalar-probe build, members running free).
+        unsigned other = 0;
+        if (a < 2) {
+            __hip_atomic_store(&ctl->cu_block[x][key][a], blockIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+            for (unsigned spins = 0; spins < (1u << 20) && !other; spins++) {
+                other = __hip_atomic_load(&ctl->cu_block[x][key][a ^ 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!other) __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        const unsigned kind = other ? (blockIdx.x + 1u < other ? 0u : 1u) : (a & 1u);   // alone on the CU: the census fails below
         s_ctl[1] = (int)x;
         s_ctl[2] = (int)kind;
         s_ctl[3] = (int)atomicAdd(&ctl->census[kind][x], 1u);
