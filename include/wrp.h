@@ -180,9 +180,10 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
                            unsigned long long *host_stamps, size_t host_count);
 
 /* Parity of the intermediate: one fused launch over n_sectors >= WRP_FUSED_MIN_SECTORS sectors, then the
- * teams' L2-resident buffers copied to host_mid[8][m/2][n] complex fp32: buffer x holds the range-FFT
- * gates < m/2 of the LAST channel-task of the team on XCD x (VV of the last sector that team owns; with
- * n_sectors = 8 on an 8-XCD device: sector x).  Must equal wrp_dump_stage(02FFT1) bit for bit. */
+ * teams' L2-resident hand-over slots copied to host_mid[8][m/4][n] complex fp32.  Slot x holds what went
+ * through it last: half 1 of the LAST channel-task of the team on XCD x (VV of the last sector that team
+ * owns; with n_sectors = 8 on an 8-XCD device: sector x) -- the range-FFT gates g < m/2 with (g mod 16) >= 8,
+ * gate g in slot row (g >> 4) * 8 + (g & 7).  Must equal those rows of wrp_dump_stage(02FFT1) bit for bit. */
 int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *host_mid, size_t host_bytes);
 
 /* Introspection for harnesses. */

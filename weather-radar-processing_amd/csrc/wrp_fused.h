@@ -1,5 +1,5 @@
 // wrp_fused.h -- the whole per-sector chain (a2 .. a9) in ONE persistent launch.  The half-height
-// intermediate of a sector-channel (2 MiB) never goes to HBM: it is handed from the range FFT to
+// intermediate of a sector-channel (2 MiB) does not go through HBM: it is handed from the range FFT to
 // the Doppler rows through the L2 of the XCD whose 32 CUs work on that sector-channel.
 //
 // Reference being replaced: rpv2.cu:409-570 (about 14 passes over a 2-4 MiB array per channel).
@@ -11,26 +11,28 @@
 //     costs 2.6 us per sector: what counts is bytes between an XCD and the fabric, not HBM hits;
 //   * input alone streams at 1.4 us per sector, so only an exchange INSIDE an XCD can get there.
 //
-// Launch: 2 x CUs workgroups of 512 threads; every CU hosts two (76 KiB of LDS each, <= 128 VGPRs).
+// Launch: 2 x CUs workgroups of 512 threads; every CU hosts two (78 KiB of LDS each, <= 128 VGPRs).
 // At start a workgroup reads the XCD and the CU it runs on (HW_REG_XCC_ID, HW_REG_HW_ID: placement
-// is READ, never assumed): the first workgroup to arrive on a CU becomes a TILE workgroup, the
-// second a ROW workgroup, so that every CU always has the HBM-bound / barrier-bound range stages of
-// one beside the VALU-bound row transforms of the other.  The workgroups of one XCD form a team of
+// is READ, never assumed): of the two workgroups of a CU the OLDER one (lower blockIdx) becomes a
+// TILE workgroup, the other a ROW workgroup, so that every CU always has the HBM-bound / barrier-bound
+// range stages of one beside the VALU-bound row transforms of the other, and the SIMDs' oldest-first
+// issue favours the tile waves (the critical path).  The workgroups of one XCD form a team of
 // 32 tile members + 32 row members; the grid meets once (census), then the teams never talk to each
 // other.  Team e owns sectors e, e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...
-//   tile member r : range tile r (columns 16 r ..) of every task  -> the team's ONE 2 MiB buffer
+//   tile member r : range tile (r + q) mod 32 (16 columns) of task q  -> the team's ONE 1 MiB slot
 //   row member r  : gates 16 r .. 16 r + 15 of every task (wave w: gates 16 r + 2 w, + 1), a4 .. a9
-// Hand-offs.  The buffer is handed over in two HALVES g = 0, 1 -- the gates with (gate mod 16) in
-// [8 g, 8 g + 8), which is exactly what k1-group g of a tile produces (see below) -- each with its own
-// pair of counters, so that a tile member never waits for the row members in steady state:
+// Hand-offs.  A task goes through the slot in two HALVES g = 0, 1 -- the gates with (gate mod 16) in
+// [8 g, 8 g + 8), which is exactly what k1-group g of a tile produces (see below); gate -> slot row
+// (gate >> 4) * 8 + (gate & 7).  Each half has its own pair of counters:
 //   stored[g] : tile members count a task's half once its stores have drained; row members wait for 32
 //   loaded[g] : row members count once their 8 rows of the half are in registers; tile members wait
-//               for 32 before they overwrite the half with the next task's
-// A tile member stores half 0 in the middle of a tile and half 1 at its end; the rows of half g are
-// loaded while the tile members transform the other half, a whole half-tile before they need the
-// space again.  Store drains are waited for where they cost nothing: half 0 behind the next tile's
-// requests (counted s_waitcnt: the loads are younger than the stores), half 1 behind the next
-// tile's stage 1.
+//               for 32 before they put the next half into the slot
+// A tile member stores half 0 in the middle of a tile and half 1 at its end; while the rows of one
+// half are loaded and transformed the tile members compute the other half.  (Two slots, one per half,
+// give each hand-over a whole task of slack -- and were slower in effect: 2 MiB rewritten per XCD do
+// not stay in the 4 MiB L2 beside the streaming input, see the look in the tile loop.)  Store drains
+// are waited for where they cost nothing: half 0 behind the next tile's requests (counted s_waitcnt:
+// the loads are younger than the stores), half 1 behind the next tile's stage 1.
 // Each counter exists in 32 replicas on lines of their own; a signalling workgroup adds to all 32
 // with ONE wave instruction and every waiter polls only ITS replica (32 workgroups polling one line
 // took 2.7 us to notice a count in round 1).  Counters are monotonic over tasks.  All of this stays
@@ -59,7 +61,8 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_MEMBERS = 32;                  // tile members = row members per team = CUs per XCD
 constexpr int FUSED_STAMP_TASKS = 16;
 constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (task 0)
-constexpr size_t FUSED_TEAM_ELEMS = (size_t)(RP_M / 2) * DP_N;   // float2 units: ONE mid[512][512] per team
+constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the gates of ONE half
+constexpr size_t FUSED_TEAM_ELEMS = (size_t)FUSED_SLOT_ROWS * DP_N;   // float2 units: ONE slot[256][512] = 1 MiB per team
 
 struct FusedLine { unsigned w; unsigned pad[31]; };   // one counter per 128-byte line
 struct FusedCtl {               // zeroed by hipMemsetAsync before every launch
@@ -315,15 +318,16 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
-    const rsrc_t rd = make_rsrc(mid, (unsigned)(RP_M / 2) * DP_N * 8u);
-    const int voff = ((w + 8 * group + 16 * (l >> 4)) * DP_N + col_base + col) * 8;
+    const rsrc_t rd = make_rsrc(mid, (unsigned)FUSED_SLOT_ROWS * DP_N * 8u);
+    // slot row of gate k1 + 16 k2 + 128 k3 (k1 = w + 8 group, k2 = (l >> 4) + 4 it): (gate >> 4) * 8 + (gate & 7)
+    const int voff = ((w + 8 * (l >> 4)) * DP_N + col_base + col) * 8;
 #pragma unroll
     for (int it = 0; it < 2; it++)
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
             v2f t;
             t.x = o[it][k3].x; t.y = o[it][k3].y;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (64 * it + 128 * k3) * DP_N * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (32 * it + 64 * k3) * DP_N * 8, 0, 0);
         }
 }
 
@@ -390,7 +394,7 @@ template <int TAPS, bool STAMPS>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
-    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: mid[512][512]
+    float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
     float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
 {
@@ -481,12 +485,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             fused_stage2(smem);
             fused_tile_load<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage3(smem, o);
-            // Half 0 of the buffer holds task q-1 until every row member has those rows in registers.  The
-            // hand-over cycle of a half -- stored, seen by the rows, loaded, seen here: about 4 us -- plus the
-            // way from this look to the next count bounds the task period from below, so the look comes as
-            // late as it can: one wave looks, in front of the barrier behind which the stores go out.
-            spin_ge_sticky(my_loaded0, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
-            __syncthreads();                    // A2: group 0 has left the image; half 0 of the buffer is free
+            // The team's ONE slot (1 MiB: the 256 gates of a half x 512 pulses) takes half 0 and half 1 of every task in
+            // turn; it still holds half 1 of task q-1 until every row member has those rows in registers.  One slot
+            // instead of one per half: a rewritten buffer of 2 MiB per XCD does not stay in the 4 MiB L2 beside the
+            // streaming input (85 % of it was written back every task, 27 % fetched again, and the latest of those
+            // row loads is what every tile member waited for); 1 MiB does -- write-backs 3.5 -> 0.5 MB per sector at
+            // the same speed.  The look comes as late as it can: one wave, in front of the barrier behind which the
+            // stores go out.
+            spin_ge_sticky(my_loaded1, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
+            __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_store(mid, tile_col(q), 0, o);
             // BEHIND the stores, so that a counted wait can tell them apart
             fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
@@ -503,9 +510,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
             fused_stage3(smem, o);
-            spin_ge_sticky(my_loaded1, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
+            spin_ge_sticky(my_loaded0, (unsigned)(FUSED_MEMBERS * (q + 1)), failed, w != 0);
             stamp(q, 7);
-            __syncthreads();                    // A4: image free for the next stage 1; half 1 of the buffer is free
+            __syncthreads();                    // A4: image free for the next stage 1; the slot is free for half 1 (the rows have half 0 of THIS task)
             fused_store(mid, tile_col(q), 1, o);
             stamp(q, 4);
         }
@@ -537,9 +544,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             if (!spin_ge(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) return;
             stamp(q, 1);
             cf x0[8], x1[8];
-            doppler_load_row<AUX_SC1>(mid + (size_t)g0 * n, l, x0);
-            doppler_load_row<AUX_SC1>(mid + (size_t)(g0 + 1) * n, l, x1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the half may be overwritten
+            const int r0 = rank * 8 + 2 * (w & 3);                 // slot rows of the gates g0, g0 + 1 (either half)
+            doppler_load_row<AUX_SC1>(mid + (size_t)r0 * n, l, x0);
+            doppler_load_row<AUX_SC1>(mid + (size_t)(r0 + 1) * n, l, x1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
             int last = 0;
             if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
             if (__builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->loaded[g][xcc], l);
