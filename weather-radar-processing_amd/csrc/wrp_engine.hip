@@ -58,7 +58,9 @@ struct wrp_engine {
     int n_cus = 0;
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_mid_pool = nullptr;   // per XCD team: ONE mid[m/2][n]
-    unsigned *h_status = nullptr;   // pinned: FusedCtl::status of every fused launch so far, OR-ed by the device copy order
+    unsigned *h_status = nullptr;   // pinned + mapped: word k % 64 is written by fused launch k itself, only when it failed
+    unsigned *d_status = nullptr;   // the same words as the device sees them
+    bool ctl_dirty = true;          // the control block needs a memset before the next fused launch (first launch, after a failure)
     int fused_launches = 0;         // launches whose status has not been looked at yet
     // batch workspace; one batch in flight per handle: the next batch's stream waits for ev_batch
     hipStream_t stream = nullptr;
@@ -237,14 +239,18 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
                  unsigned long long *d_stamps = nullptr)
 {
     const wrp_config &c = h->cfg;
-    HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
+    // a successful launch leaves the control block zeroed (fused_leave): no memset node in front of the next one
+    if (h->ctl_dirty) {
+        HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
+        h->ctl_dirty = false;
+    }
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
     // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
 #define WRP_FUSED(TAPS, STAMPS)                                                                                       \
     hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n_arr, n_sectors, \
-                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, d_stamps)
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + h->fused_launches % 64, d_stamps)
     if (d_stamps) {
         if (h->taps_pad == 7) WRP_FUSED(7, true); else WRP_FUSED(9, true);
     } else {
@@ -252,9 +258,7 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     }
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
-    // the status word of this launch lands in its own pinned slot; looked at by check_fused()
-    HIP_TRY(h, hipMemcpyAsync(&h->h_status[h->fused_launches % 64], &h->d_ctl->status, sizeof(unsigned),
-                              hipMemcpyDeviceToHost, st));
+    // a launch that fails says so in its own pinned word (written from the kernel); looked at by check_fused()
     h->fused_launches++;
     return WRP_OK;
 }
@@ -270,6 +274,7 @@ int check_fused(wrp_engine *h)
     h->fused_launches = 0;
     if (!bad) return WRP_OK;
     h->fused = false;
+    h->ctl_dirty = true;
     h->hip_err = (bad & 2) ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; handle switched to the two-kernel path"
                            : "fused launch: a bounded wait gave up (workgroups not co-resident?); handle switched to the two-kernel path";
     return WRP_ERR_HIP;
@@ -356,8 +361,9 @@ int create_impl(wrp_engine *h)
 #undef WRP_FUSED_ATTR
     HIP_TRY(h, hipMalloc(&h->d_ctl, sizeof(wrp::FusedCtl)));
     HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8));
-    HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * 64, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * 64, hipHostMallocMapped));
     std::memset(h->h_status, 0, sizeof(unsigned) * 64);
+    HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_status, h->h_status, 0));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<16>::LDS_BYTES));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, true>),

@@ -65,12 +65,13 @@ constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the g
 constexpr size_t FUSED_TEAM_ELEMS = (size_t)FUSED_SLOT_ROWS * DP_N;   // float2 units: ONE slot[256][512] = 1 MiB per team
 
 struct FusedLine { unsigned w; unsigned pad[31]; };   // one counter per 128-byte line
-struct FusedCtl {               // zeroed by hipMemsetAsync before every launch
-    unsigned arrived;           // grid-wide start counter
-    unsigned status;            // 0 ok; 1: a bounded spin gave up; 2: a team is not 32 + 32 workgroups
+struct FusedCtl {               // zeroed by the host once; every launch leaves it zeroed again (the teams' last workgroups)
+    unsigned unused0;
+    unsigned status;            // 0 ok; 1: a bounded spin gave up; 2: a team is not 32 + 32 workgroups.  Sticky: the host zeroes the block after a failure
     unsigned pad0[30];
     unsigned census[2][8];      // workgroups per kind (0 tile, 1 row) and XCC
-    unsigned pad1[16];
+    unsigned done[8];           // workgroups of the XCC's team that have left the task loop
+    unsigned pad1[8];
     unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
     unsigned cu_block[8][256][2];            // blockIdx + 1 of the first and the second workgroup to arrive there
     FusedLine stored[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: tile halves stored so far; polled by row member r only
@@ -331,53 +332,56 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
         }
 }
 
-// Who am I: XCD, kind (the older / the younger of the two workgroups on this CU), rank inside the team; the grid meets
-// once (census), afterwards the teams never talk to each other.  Every thread of the workgroup calls.
+// Who am I: XCD, kind (the older / the younger of the two workgroups on this CU), rank inside the team.  Everything here
+// stays inside the XCD (L2 atomics of workgroup scope, polls served by that L2): a team needs no other team.  The first
+// version met grid-wide (agent-scope arrivals with release, 512 pollers on one word): 31-35 us of every launch.
+// What makes the local form sufficient: a CU holds at most two of these workgroups (LDS), so an XCD holds at most 64;
+// a grid of 64 T workgroups on T XCDs that are all resident therefore puts exactly two on every CU -- one older (tile),
+// one younger (row) -- and 32 + 32 on every XCD.  A team waits (bounded) until ITS census says so; XCC ids must be
+// 0 .. T-1 (team x owns sectors x, x + T, ...).  Anything else -- another kernel on the GPU, a partitioned device, the
+// undersized test launch -- ends in status 2 and the engine's two-kernel path.
 struct FusedSeat { int ok, xcc, kind, rank, teams, trank; };
 __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
 {
     const int tid = threadIdx.x;
     if (tid == 0) {
         const unsigned x = xcc_id(), key = hw_cu_key();
-        const unsigned a = atomicAdd(&ctl->cu_arrivals[x][key], 1u);
+        const unsigned a = __hip_atomic_fetch_add(&ctl->cu_arrivals[x][key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // The two workgroups of a CU meet: the OLDER one (lower blockIdx: dispatched first) is the tile workgroup.
         // A SIMD issues from its oldest ready wave first, and the tile waves are the critical path of a task; where
         // the younger workgroup had the tile role (it wins the race to the counter on ~3 % of the CUs), that member
         // ran 10 % slower than the others for the whole launch (scalar-probe build, members running free).
         unsigned other = 0;
         if (a < 2) {
-            __hip_atomic_store(&ctl->cu_block[x][key][a], blockIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->cu_block[x][key][a], blockIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll 1
-            for (unsigned spins = 0; spins < (1u << 20) && !other; spins++) {
-                other = __hip_atomic_load(&ctl->cu_block[x][key][a ^ 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (unsigned spins = 0; spins < (1u << 16) && !other; spins++) {
+                other = __hip_atomic_load(&ctl->cu_block[x][key][a ^ 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: from the L2
                 if (!other) __builtin_amdgcn_s_sleep(4);
             }
         }
-        const unsigned kind = other ? (blockIdx.x + 1u < other ? 0u : 1u) : (a & 1u);   // alone on the CU: the census fails below
+        const unsigned kind = other ? (blockIdx.x + 1u < other ? 0u : 1u) : (a & 1u);
+        const unsigned rank = __hip_atomic_fetch_add(&ctl->census[kind][x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned teams = gridDim.x / (2u * FUSED_MEMBERS);
+        int good = other != 0 && x < teams && gridDim.x == teams * 2u * FUSED_MEMBERS;
+        if (good) {   // the team meets: both kinds complete
+            good = 0;
+#pragma unroll 1
+            for (unsigned spins = 0; spins < (1u << 20); spins++) {
+                const unsigned ct = __hip_atomic_load(&ctl->census[0][x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned cr = __hip_atomic_load(&ctl->census[1][x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ct + cr >= 2u * FUSED_MEMBERS) { good = ct == (unsigned)FUSED_MEMBERS && cr == (unsigned)FUSED_MEMBERS; break; }
+                if (__hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (!good) __hip_atomic_store(&ctl->status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ctl[0] = good;
         s_ctl[1] = (int)x;
         s_ctl[2] = (int)kind;
-        s_ctl[3] = (int)atomicAdd(&ctl->census[kind][x], 1u);
-        __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        // the grid meets once: afterwards the census is final
-        int good = 0;
-#pragma unroll 1
-        for (unsigned spins = 0; spins < (1u << 22); spins++) {
-            if (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { good = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        int teams = 0, trank = 0;
-        for (unsigned y = 0; y < 8; y++) {
-            const unsigned ct = __hip_atomic_load(&ctl->census[0][y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned cr = __hip_atomic_load(&ctl->census[1][y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ct + cr == 0) continue;
-            if (ct < (unsigned)FUSED_MEMBERS || cr < (unsigned)FUSED_MEMBERS) good = good ? 2 : 0;   // a team that cannot work
-            if (y < x) trank++;
-            teams++;
-        }
-        if (good != 1) __hip_atomic_store(&ctl->status, good == 2 ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ctl[0] = good == 1;
-        s_ctl[4] = teams;
-        s_ctl[5] = trank;
+        s_ctl[3] = (int)rank;
+        s_ctl[4] = (int)teams;
+        s_ctl[5] = (int)x;
     }
     __syncthreads();
     FusedSeat r;   // wave-uniform by construction; readfirstlane tells the compiler so (scalar address arithmetic)
@@ -390,13 +394,43 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
     return r;
 }
 
+// The end of a workgroup's work.  Failure: tell the host (a word in pinned host memory; nothing is copied back after a
+// launch).  Success: the last of the team's 64 workgroups to get here zeroes the team's part of the control block, so
+// the next launch needs no memset in front of it.
+__device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status, int xcc, lds_word *s_ctl)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned st = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st) __hip_atomic_store(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_ctl[6] = !st && __hip_atomic_fetch_add(&ctl->done[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2u * FUSED_MEMBERS - 1u;
+    }
+    __syncthreads();
+    if (!s_ctl[6]) return;
+    uint4 *z;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    for (int g = 0; g < 2; g++) {
+        z = reinterpret_cast<uint4 *>(ctl->stored[g][xcc]);
+        for (int e = tid; e < (int)(FUSED_MEMBERS * sizeof(FusedLine) / 16); e += FUSED_THREADS) z[e] = zero;
+        z = reinterpret_cast<uint4 *>(ctl->loaded[g][xcc]);
+        for (int e = tid; e < (int)(FUSED_MEMBERS * sizeof(FusedLine) / 16); e += FUSED_THREADS) z[e] = zero;
+    }
+    z = reinterpret_cast<uint4 *>(ctl->cu_arrivals[xcc]);
+    for (int e = tid; e < 256 / 4; e += FUSED_THREADS) z[e] = zero;
+    z = reinterpret_cast<uint4 *>(ctl->cu_block[xcc]);
+    for (int e = tid; e < 512 / 4; e += FUSED_THREADS) z[e] = zero;
+    if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; }
+}
+
 template <int TAPS, bool STAMPS>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
-    float k_rr, float k_cal, unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
+    float k_rr, float k_cal, unsigned *host_status /* pinned host word of this launch */,
+    unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
 {
     typedef FusedTile T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -405,9 +439,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
     const int n = DP_N, gates = RP_M / 2;
 
     const FusedSeat seat = fused_join(ctl, s_ctl);
-    if (!seat.ok) return;
     const int xcc = seat.xcc, kind = seat.kind, rank = seat.rank, teams = seat.teams, trank = seat.trank;
-    if (rank >= FUSED_MEMBERS) return;   // surplus workgroups own nothing
+    if (!seat.ok || rank >= FUSED_MEMBERS) {   // no team, or a surplus workgroup (then the census has failed too)
+        fused_leave(ctl, host_status, xcc, s_ctl);
+        return;
+    }
     const int tasks = 2 * ((n_sectors - trank + teams - 1) / teams);   // channel-tasks of this team
     float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
     // diagnostics build only: stamps go to LDS (no vector-memory traffic in the timed phases) and
@@ -521,6 +557,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         if (tasks > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
         if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flush_stamps();
+        fused_leave(ctl, host_status, xcc, s_ctl);
     } else {
         // =============================== row member ===============================
         // Eight independent waves, no workgroup barrier in the loop: waves 0-3 own the member's 8 gates
@@ -541,7 +578,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             stamp(q, 0);
-            if (!spin_ge(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) return;
+            if (!spin_ge(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) break;   // status is set: the launch is void
             stamp(q, 1);
             cf x0[8], x1[8];
             const int r0 = rank * 8 + 2 * (w & 3);                 // slot rows of the gates g0, g0 + 1 (either half)
@@ -565,6 +602,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             }
         }
         flush_stamps();
+        fused_leave(ctl, host_status, xcc, s_ctl);
     }
 }
 
