@@ -142,8 +142,8 @@ def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, oracle, sectors):
     """The default for batches of >= 8 sectors: ONE persistent launch, tile + row workgroups on every CU,
     XCD teams handing the intermediate over through their L2 (csrc/wrp_fused.h).  It performs the arithmetic
     of the two-kernel path element for element, so the results must agree BIT FOR BIT -- for batch sizes
-    that do and do not divide evenly among the teams, when the engine is reused (control block re-zeroed
-    per launch), and against the fp64 oracle."""
+    that do and do not divide evenly among the teams, when the engine is reused (every launch leaves the
+    control block zeroed for the next one: there is no memset between them), and against the fp64 oracle."""
     with wrp.Engine(device=0, n_slots=1) as ef, wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
         for count in (8, 19, 50):
             batch = np.stack([sectors[(3 * k + 1) % 3] * np.float32(1 + 0.25 * (k % 5)) for k in range(count)])

@@ -3,10 +3,10 @@
 Every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 8 of task 0 holds
 kind << 32 | xcc << 16 | rank.
   tile workgroups: 0 task start, 1 stage 1 done (barrier A1), [quarters 0-1 requested, stages 2-3 of group 0,
-                   half 0 seen free (wave 0), A2, stores: no stamp here -- any stamp between A1 and the
-                   stores makes hipcc spill 30-40 registers], 2 quarter 2 requested + group 1 written,
-                   6 half 0 drained and counted, 3 A3, 7 quarter 3 requested, stages 2-3 of group 1 done, half 1
-                   seen free, 4 A4 + stores issued
+                   look A: the slot is free of the previous task's half 1 (wave 0), A2, stores: no stamp here -- any
+                   stamp between A1 and the stores makes hipcc spill 30-40 registers], 2 quarter 2 requested + group 1
+                   written, 6 half 0 drained and counted, 3 A3, 7 quarter 3 requested, stages 2-3 of group 1 done, look B:
+                   the rows have half 0 of THIS task, 4 A4 + stores of half 1 issued
   row workgroups : wave 0 (half 0) slots 0-3, wave 4 (half 1) slots 4-7: + 0 task start, + 1 half stored by
                    all tiles, + 2 rows in registers and counted, + 3 rows transformed
 Read the SHARES, not the length: stamps forbid overlaps the real launch has."""
@@ -47,8 +47,8 @@ def main():
     t = st.astype(np.float64) / 100.0     # us
     tasks = min(16, 2 * (S // 8))
     r = slice(3, tasks)
-    names = {0: ["stage 1 .. A1", "A1 .. group 1 in LDS (Q0, stage 2, Q1, stage 3, look, A2, stores, Q2, write)",
-                 "drain half 0, count .. A3", "A3 .. A4 + stores (Q3, stage 2, stage 3, look, A4, stores)"],
+    names = {0: ["stage 1 .. A1", "A1 .. group 1 in LDS (Q0, stage 2, Q1, stage 3, look A, A2, stores, Q2, write)",
+                 "drain half 0, count .. A3", "A3 .. A4 + stores (Q3, stage 2, stage 3, look B = wait for the rows of half 0, A4, stores)"],
              1: ["half 0: wait stored", "half 0: row loads + count", "half 0: two row transforms",
                  "(wave 0 -> wave 4)", "half 1: wait stored", "half 1: row loads + count", "half 1: two row transforms"]}
     for k, label in ((0, "tile"), (1, "row")):
@@ -56,9 +56,9 @@ def main():
         d = np.diff(t[sel][:, r, :len(names[k]) + 1], axis=2)
         if k == 0:
             x = t[sel][:, r, :]
-            print(f"    (A1 -> stages 2-3 + look 0 + A2 + stores + Q2 + write {np.median(x[:, :, 2] - x[:, :, 1]):.2f}, "
+            print(f"    (A1 -> stages 2-3 + look A + A2 + stores + Q2 + write {np.median(x[:, :, 2] - x[:, :, 1]):.2f}, "
                   f"drain + count {np.median(x[:, :, 6] - x[:, :, 2]):.2f}, barrier A3 {np.median(x[:, :, 3] - x[:, :, 6]):.2f}, "
-                  f"A3 -> stages 2-3 + look 1 {np.median(x[:, :, 7] - x[:, :, 3]):.2f}, A4 + stores {np.median(x[:, :, 4] - x[:, :, 7]):.2f})")
+                  f"A3 -> stages 2-3 + look B {np.median(x[:, :, 7] - x[:, :, 3]):.2f}, A4 + stores {np.median(x[:, :, 4] - x[:, :, 7]):.2f})")
         print(f"{label} workgroups ({int(sel.sum())}), tasks 3..{tasks - 1}; median (p10 .. p90) us")
         for i, nm in enumerate(names[k]):
             x = d[:, :, i].ravel()
