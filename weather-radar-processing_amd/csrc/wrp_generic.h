@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void generic_doppler_pass(
             if (do_dump && dump.noshift) dump.noshift[(size_t)gate * n + k] = make_float2(z.x, -z.y);
             if (j >= n - 2) z = make_float2(0.f, 0.f);
             if (do_dump && dump.fft2) dump.fft2[(size_t)gate * n + j] = z;
-            const float a = z.x * z.x + z.y * z.y;
+            const float a = fmaf(z.y, z.y, z.x * z.x);
             abuf[j] = a;
             if (do_dump && dump.abs2) dump.abs2[(size_t)gate * n + j] = a;
         }

@@ -460,26 +460,34 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
         t1[k] = tw[k * 64 + l];
         t2[k] = tw[512 + k * 8 + (l & 7)];
     }
+    // LDS positions below are written as `lane base + compile-time offset`: with l < 64, p1, k2 < 8 the padded index
+    // dp_idx(pos) = pos + 2 (pos >> 4) is linear in the unrolled counter (one address register per stage, immediates
+    // for the eight elements), which the compiler does not find by itself:
+    //   dp_idx(k1 64 + l)            = dp_idx(l) + 72 k1
+    //   dp_idx(k1 64 + p1 + 8 r)     = 72 k1 + p1 + 8 r + 2 (r >> 1)
+    //   dp_idx(k1 64 + 8 k2 + r)     = 72 k1 + 8 k2 + 2 (k2 >> 1) + r
     fft8<+1>(v);                                   // stage 1: lane l owns j = l + 64 r
-    buf[dp_idx(l)] = v[0];
+    const int b1 = dp_idx(l);
+    buf[b1] = v[0];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) buf[dp_idx(k1 * 64 + l)] = cmul(v[k1], t1[k1]);
+    for (int k1 = 1; k1 < 8; k1++) buf[b1 + 72 * k1] = cmul(v[k1], t1[k1]);
     wave_lds_fence();
     {                                              // stage 2: lane = p1 + 8 k1, positions k1*64 + p1 + 8 r
-        const int p1 = l & 7, k1 = l >> 3;
+        const int b2 = 72 * (l >> 3) + (l & 7);
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = buf[dp_idx(k1 * 64 + p1 + 8 * r)];
+        for (int r = 0; r < 8; r++) v[r] = buf[b2 + 8 * r + 2 * (r >> 1)];
         fft8<+1>(v);
-        buf[dp_idx(k1 * 64 + p1)] = v[0];
+        buf[b2] = v[0];
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) buf[dp_idx(k1 * 64 + p1 + 8 * k2)] = cmul(v[k2], t2[k2]);
+        for (int k2 = 1; k2 < 8; k2++) buf[b2 + 8 * k2 + 2 * (k2 >> 1)] = cmul(v[k2], t2[k2]);
     }
     wave_lds_fence();
     // stage 3: lane = k2 + 8 k1 owns positions k1*64 + k2*8 + r; output k = k1 + 8 k2 + 64 k3
     const int k2 = l & 7, k1 = l >> 3;
     const int klo = k1 + 8 * k2;
+    const int b3 = 72 * k1 + 8 * k2 + 2 * (k2 >> 1);
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = buf[dp_idx(k1 * 64 + k2 * 8 + r)];
+    for (int r = 0; r < 8; r++) v[r] = buf[b3 + r];
     fft8<+1>(v);
     wave_lds_fence();   // everyone has read before the buffer is reused for |.|^2
 
@@ -489,13 +497,14 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
             dump.noshift[(size_t)gate * DP_N + klo + 64 * k3] = make_float2(v[k3].x, -v[k3].y);
     }
     // shift (swap halves: j = k + n/2 mod n), clip post-shift bins n-1, n-2, |.|^2
+    const int fb = klo + 4 * (klo >> 3);
 #pragma unroll
     for (int k3 = 0; k3 < 8; k3++) {
         const int j = ((k3 + 4) & 7) * 64 + klo;
         cf z = v[k3];
         if (j >= DP_N - 2) z = make_float2(0.f, 0.f);
         if (DUMP && do_dump && dump.fft2) dump.fft2[(size_t)gate * DP_N + j] = z;
-        fbuf[dp_fidx(j)] = z.x * z.x + z.y * z.y;
+        fbuf[fb + 96 * ((k3 + 4) & 7)] = fmaf(z.y, z.y, z.x * z.x);   // = dp_fidx(j): j + 4 (j >> 3) with klo < 64
     }
     wave_lds_fence();
     // a7: P[j] = sum_t g[t] A[(j - t) mod n]; lane owns j = 8 l .. 8 l + 7 plus an 8-bin halo

@@ -277,7 +277,7 @@ __device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const 
                 const int j = (k + RB_N / 2) & (RB_N - 1);
                 cf z = v[4 * it + k3];
                 if (j >= RB_N - 2) z = make_float2(0.f, 0.f);
-                fbuf[db_fidx(j)] = z.x * z.x + z.y * z.y;
+                fbuf[db_fidx(j)] = fmaf(z.y, z.y, z.x * z.x);
             }
         }
     }
