@@ -41,20 +41,35 @@ def STAGE_SHAPES(m, n):
     }
 
 
+def _code_only(text):
+    """C/C++ source without comments and without the whitespace around tokens: what the compiler sees."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = []
+    for line in text.split("\n"):
+        # a // inside a string literal never occurs in these sources except in asm comment markers ("; ..."), which use ';'
+        line = re.sub(r"//.*$", "", line)
+        line = " ".join(line.split())
+        if line:
+            out.append(line)
+    return "\n".join(out)
+
+
 def source_fingerprint():
-    """sha256 over the sources libwrp.so is built from (csrc/, include/wrp.h, the Makefile's flags): ties a
-    committed rocprof summary (profiles/rNN/traffic.json) to the code it was measured on."""
+    """sha256 over the CODE libwrp.so is built from (csrc/ and include/wrp.h without comments and layout, the Makefile's
+    compiler flags): ties a committed rocprof summary (profiles/rNN/traffic.json) to the code it was measured on.  Editing
+    a comment does not invalidate a measurement; editing an instruction does."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.listdir(os.path.join(_PKG, "csrc")))
     for f in files:
         if f.endswith((".h", ".hip")):
             h.update(f.encode())
-            h.update(open(os.path.join(_PKG, "csrc", f), "rb").read())
-    h.update(open(os.path.join(_ROOT, "include", "wrp.h"), "rb").read())
+            h.update(_code_only(open(os.path.join(_PKG, "csrc", f)).read()).encode())
+    h.update(_code_only(open(os.path.join(_ROOT, "include", "wrp.h")).read()).encode())
     for line in open(os.path.join(_ROOT, "Makefile")):
         if line.startswith("HIPFLAGS"):
-            h.update(line.encode())
+            h.update(" ".join(line.split()).encode())
     return h.hexdigest()[:16]
 
 

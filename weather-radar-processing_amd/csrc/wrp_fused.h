@@ -29,8 +29,8 @@
 //               for 32 before they put the next half into the slot
 // A tile member stores half 0 in the middle of a tile and half 1 at its end; while the rows of one
 // half are loaded and transformed the tile members compute the other half.  (Two slots, one per half,
-// give each hand-over a whole task of slack -- and were slower in effect: 2 MiB rewritten per XCD do
-// not stay in the 4 MiB L2 beside the streaming input, see the look in the tile loop.)  Store drains
+// give each hand-over a whole task of slack -- and were no faster: 2 MiB rewritten per XCD do not stay
+// in the 4 MiB L2 beside the streaming input, see the look in the tile loop.)  Store drains
 // are waited for where they cost nothing: half 0 behind the next tile's requests (counted s_waitcnt:
 // the loads are younger than the stores), half 1 behind the next tile's stage 1.
 // Each counter exists in 32 replicas on lines of their own; a signalling workgroup adds to all 32
@@ -39,7 +39,9 @@
 // inside one XCD, whose L2 is the point of coherence for its own CUs: tiles are stored with plain
 // stores (the lines stay in that L2) and drained with s_waitcnt vmcnt(0) before the count; rows and
 // counters are read with loads that miss the reader's L1 (sc1).  The input is read non-temporally so
-// that it does not push the buffer out of the L2.  Every spin is bounded; a timeout or a team that
+// that it does not push the slot out of the L2.  Counters are polled with scalar loads (glc): scalar
+// memory has its own path and counter, a vector poll would queue behind the CU's tile requests.  Every
+// spin is bounded; a timeout or a team that
 // is not 32 + 32 is reported in FusedCtl::status and the engine falls back to the two-kernel path.
 //
 // Range FFT: exactly the arithmetic of range_pass_1024<16> (1024 = 16 x 8 x 8, same butterflies,
@@ -49,7 +51,7 @@
 // entirely in wave k1 mod 8 for stages 2 and 3.  So the tile goes through LDS in two GROUPS of
 // eight k1 (72 KiB instead of 144 KiB -- which is what lets two workgroups share a CU with
 // 16-column tiles, i.e. whole 128-byte lines); group 1 waits in 32 registers meanwhile, and only
-// the hand-over from stage 1 needs workgroup barriers (5 per tile, one of them for a count).
+// the hand-over from stage 1 needs workgroup barriers (4 per tile; the counts use LDS arrival counters).
 #pragma once
 #include <hip/hip_runtime.h>
 
