@@ -30,6 +30,35 @@ def test_sector_from_byte_array(host, golden):
     assert np.array_equal(hh, z["hh"]) and np.array_equal(vv, z["vv"]) and np.array_equal(vh, z["vh"])
 
 
+def test_sector_read_takes_every_byte_of_the_stream(host, golden):
+    """Sector::read is the stream form of fromByteArray.  The reference extracts its bytes with `in >> char`
+    (sector.cpp:26-45), which SKIPS bytes that happen to be whitespace (0x09-0x0d, 0x20) -- in binary IQ data that
+    shifts every later sample.  Here the stream is read unformatted: the same samples as fromByteArray whatever the
+    byte values, and a stream that ends early leaves the rest of the sector untouched."""
+    z = golden("ref_host_codecs.npz")
+    sw, sa = int(z["sweeps"]), int(z["samples"])
+    raw = np.array(z["raw"], dtype=np.uint8).copy()
+    raw[5::7] = 0x20                       # plenty of "whitespace" inside the samples
+    raw[3::11] = 0x0A
+    sp = C.POINTER(C.c_short)
+
+    def run(fn, *args):
+        hh = np.zeros(2 * sw * sa, np.int16); vv = np.zeros_like(hh); vh = np.zeros_like(hh)
+        fn(*args, sw, sa, hh.ctypes.data_as(sp), vv.ctypes.data_as(sp), vh.ctypes.data_as(sp))
+        return hh, vv, vh
+
+    want = run(host.wrph_sector_from_bytes, (C.c_char * raw.size).from_buffer_copy(raw.tobytes()))
+    host.wrph_sector_read.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, sp, sp, sp]
+    got = run(host.wrph_sector_read, raw.tobytes(), raw.size)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # a stream that ends in the middle of sample k: samples < k as above, nothing behind them
+    k = (sw * sa) // 3
+    short = run(host.wrph_sector_read, raw.tobytes()[: 12 * k + 5], 12 * k + 5)
+    for a, b in zip(short, want):
+        assert np.array_equal(a[: 2 * k], b[: 2 * k]) and not a[2 * k:].any()
+
+
 def test_floats_big_endian_round_trip(host, golden):
     z = golden("ref_host_codecs.npz")
     fl = np.ascontiguousarray(z["floats"])

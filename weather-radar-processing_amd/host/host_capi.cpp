@@ -3,6 +3,8 @@
 
 #include <chrono>
 #include <memory>
+#include <sstream>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -19,6 +21,21 @@ void wrph_sector_from_bytes(char *buff, int sweeps, int samples, short *hh, shor
     Sector s(sweeps, samples);
     s.fromByteArray(buff);
     const size_t cnt = sizeof(short) * 2 * (size_t)sweeps * samples;
+    memcpy(hh, s.hh, cnt);
+    memcpy(vv, s.vv, cnt);
+    memcpy(vh, s.vh, cnt);
+}
+// Sector::read from a stream holding `nbytes` bytes (sector.cpp:26-45 in the reference).  The sector is zero-filled
+// first, so a short stream shows as zeros behind the last whole sample.
+void wrph_sector_read(const char *bytes, size_t nbytes, int sweeps, int samples, short *hh, short *vv, short *vh)
+{
+    Sector s(sweeps, samples);
+    const size_t cnt = sizeof(short) * 2 * (size_t)sweeps * samples;
+    memset(s.hh, 0, cnt);
+    memset(s.vv, 0, cnt);
+    memset(s.vh, 0, cnt);
+    std::istringstream in(std::string(bytes, nbytes));
+    s.read(in);
     memcpy(hh, s.hh, cnt);
     memcpy(vv, s.vv, cnt);
     memcpy(vh, s.vh, cnt);
