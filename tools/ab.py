@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""A/B timing of two BUILDS of libwrp.so in ONE process, rounds interleaved (the boxes differ by +-3 % and a run of
+tune.py per build by +-1.5 %: too coarse for a 1 % change).
+
+  python tools/ab.py build/exp/libs/libwrp_A.so build/exp/libs/libwrp_B.so [--sectors 360] [--rounds 40] [--iters 10]
+
+Each library is dlopen'ed under its own path (two independent instances), gets one engine on device 0 and the same
+input; reports the median us/sector of each and the paired difference B - A with its standard error.
+Caveat, measured: two engines of the SAME build differ by up to 0.8 % here (standard error 0.05 %) -- where an engine's
+slots and control block land in memory matters that much; give the same library twice to see the floor on a box."""
+import argparse
+import ctypes as C
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--sectors", type=int, default=360)
+    ap.add_argument("--rounds", type=int, default=40)
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import wrp_amd
+    from wrp_amd import binding as B
+    from oracle import oracle as O
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.init()
+    S = args.sectors
+    pool = np.stack([O.synthetic_sector(k) for k in range(4)])
+    d_pool = torch.from_numpy(pool.view(np.float32).reshape(4, -1)).to(dev)
+    d_iq = d_pool[torch.arange(S, device=dev) % 4].contiguous()
+    d_out = torch.empty((S, 512, 2), dtype=torch.float32, device=dev)
+    want = O.sector(pool[1][0], pool[1][1], dtype=np.float64)
+
+    engines = []
+    for path in args.libs:
+        B._LIB = None
+        B.lib_path = (lambda p: (lambda: p))(os.path.abspath(path))     # the binding's loader, pointed at this build
+        e = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1)
+        e.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
+        torch.cuda.synchronize()
+        ok = bool(np.max(np.abs(d_out[1].cpu().numpy()[1:] - want[1:])) < 1e-3)
+        engines.append((os.path.basename(path), e, ok, []))
+    k = 1e3 / (args.iters * S)
+    for _ in range(5):                                    # settle
+        for _, e, _, _ in engines:
+            e.time_batch_device(d_iq.data_ptr(), S, d_out.data_ptr(), args.iters, per_kernel=False)
+    for r in range(args.rounds):
+        order = engines if r % 2 == 0 else engines[::-1]
+        for _, e, _, tt in order:
+            t = e.time_batch_device(d_iq.data_ptr(), S, d_out.data_ptr(), args.iters, per_kernel=False)
+            tt.append((t[0] if isinstance(t, tuple) else t) * k)
+    base = engines[0][3]
+    for name, e, ok, tt in engines:
+        d = [b - a for a, b in zip(base, tt)]
+        sem = statistics.pstdev(d) / len(d) ** 0.5
+        print(f"{name:28s} ok={ok}  median {statistics.median(tt):6.3f}  mean {statistics.fmean(tt):6.3f} us/sector   "
+              f"vs {engines[0][0]}: {statistics.fmean(d):+7.4f} +- {sem:6.4f}  ({100 * statistics.fmean(d) / statistics.fmean(base):+5.2f} %)")
+
+
+if __name__ == "__main__":
+    main()
