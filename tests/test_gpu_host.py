@@ -142,3 +142,39 @@ def test_rpv2_udp_ingest_and_egress_on_loopback(oracle):
                 assert np.isneginf(vals[0]) and np.max(np.abs(vals[1:] - want[1:, 0]) / np.abs(want[1:, 0])) < 1e-5
             else:
                 assert np.max(np.abs(vals - want[:, 1])) < 2e-5
+
+
+READ_ALTB = os.path.join(ROOT, "weather-radar-processing_amd", "host", "read_altb")
+M = 1024
+
+
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_read_altb_is_read_cc_with_the_gpu_behind_it(tmp_path, oracle, with_ids):
+    """read.cc's own interface: text sectors on stdin (m*n pairs "I Q" of HH, then of VV: read.cc:106-123; the
+    multi-sector variant carries a sector id in front of each, gpu_1fp_streamreordered.cu:290-302), one line
+    "zdb zdr" per gate on stdout (read.cc:344, ostream default formatting = 6 significant digits).  Three synthetic
+    sectors (so that both pinned slots are reused) against the fp64 oracle."""
+    assert os.path.exists(READ_ALTB), "run `make host`"
+    K = 3
+    secs = [oracle.synthetic_sector(10 + k) for k in range(K)]          # [2][m][n] complex64, int16-valued
+    parts = []
+    for k, s in enumerate(secs):
+        flat = s.view(np.float32).reshape(-1).astype(np.int64)           # HH (re, im) row-major, then VV: the text order
+        if with_ids:
+            parts.append(str(100 + k))
+        parts.append(" ".join(map(str, flat.tolist())))
+    text = "\n".join(parts) + "\n"
+    r = subprocess.run([READ_ALTB], input=text, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[float(x) for x in line.split()] for line in r.stdout.strip().split("\n")], dtype=np.float64)
+    assert got.shape == (K * M // 2, 2)
+    for k, s in enumerate(secs):
+        want = oracle.sector(s[0], s[1], dtype=np.float64)
+        g = got[k * (M // 2):(k + 1) * (M // 2)]
+        assert np.isneginf(g[0, 0])
+        # 6 printed digits of values up to ~100 dB: 5e-4 dB of print quantisation on top of the usual tolerances
+        assert np.max(np.abs(g[1:, 0] - want[1:, 0])) < 1e-3
+        assert np.max(np.abs(g[1:, 1] - want[1:, 1])) < 1e-4
+    # a truncated file is refused, not misread
+    r = subprocess.run([READ_ALTB], input="1 2 3\n", capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "expected a multiple" in r.stderr
