@@ -8,6 +8,7 @@
 //   1  per-writer flag words: signaller r stores the round number into word r of each of the 32 waiters' lines (one wave
 //      instruction, plain stores), a waiter polls its whole line (two s_load_dwordx16 glc) and takes the minimum
 //   2  as 0, polled with a vector load (sc1)       3  as 1, polled with one 32-lane vector load (sc1) + DPP-free min by ballot
+//   4  as 0, polled with s_dcache_inv + an ordinary scalar load (no glc)      5  as 1, polled the same way
 // Prints us per round trip (= two notifications), idle chip.
 // Build: hipcc -O3 --offload-arch=gfx950 -o build/tools/hopbench tools/hopbench.hip
 #include <hip/hip_runtime.h>
@@ -25,6 +26,23 @@ __device__ __forceinline__ unsigned peek1(unsigned *p)
     asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
+__device__ __forceinline__ unsigned peek1_inv(unsigned *p)   // invalidate the scalar cache, then an ordinary (L2-served) scalar load
+{
+    unsigned v;
+    asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned peek_min32_inv(Line *p)
+{
+    v16u a, b;
+    asm volatile("s_dcache_inv\n\ts_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+    unsigned m = a[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) m = m < a[i] ? m : a[i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m = m < b[i] ? m : b[i];
+    return m;
+}
 __device__ __forceinline__ unsigned peek_min32(Line *p)
 {
     v16u a, b;
@@ -40,7 +58,7 @@ template <int FORM>
 __device__ __forceinline__ void signal(Line *lines, int rank, unsigned round, int l)
 {
     if (l < 32) {
-        if (FORM == 0 || FORM == 2) __hip_atomic_fetch_add(&lines[l].w[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (FORM == 0 || FORM == 2 || FORM == 4) __hip_atomic_fetch_add(&lines[l].w[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(&lines[l].w[rank], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
@@ -49,6 +67,8 @@ __device__ __forceinline__ bool wait_all(Line *mine, unsigned round, int l)
 {
     for (unsigned spins = 0; spins < (1u << 22); spins++) {
         if (FORM == 0) { if (peek1(&mine->w[0]) >= 32u * round) return true; }
+        else if (FORM == 4) { if (peek1_inv(&mine->w[0]) >= 32u * round) return true; }
+        else if (FORM == 5) { if (peek_min32_inv(mine) >= round) return true; }
         else if (FORM == 1) { if (peek_min32(mine) >= round) return true; }
         else if (FORM == 2) { if (__hip_atomic_load(&mine->w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 32u * round) return true; }
         else {
@@ -94,6 +114,6 @@ int main(int argc, char **argv)
         CK(hipMemcpy(&h, d, sizeof(Ctl), hipMemcpyDeviceToHost)); double s = 0; int n = 0; \
         for (int x = 0; x < 8; x++) if (h.t[x][1]) { s += (h.t[x][1] - h.t[x][0]) / 100.0 / rounds; n++; } \
         printf("form %d: %.3f us per round trip (%d teams, bad %u)\n", F, n ? s / n : 0.0, n, h.bad); } while (0)
-    RUN(0); RUN(1); RUN(2); RUN(3); RUN(0); RUN(1);
+    RUN(0); RUN(1); RUN(2); RUN(3); RUN(4); RUN(5); RUN(0);
     return 0;
 }

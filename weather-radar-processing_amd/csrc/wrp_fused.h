@@ -17,32 +17,32 @@
 // TILE workgroup, the other a ROW workgroup, so that every CU always has the HBM-bound / barrier-bound
 // range stages of one beside the VALU-bound row transforms of the other, and the SIMDs' oldest-first
 // issue favours the tile waves (the critical path).  The workgroups of one XCD form a team of
-// 32 tile members + 32 row members; the grid meets once (census), then the teams never talk to each
+// 32 tile members + 32 row members; a team meets once (its census), teams never talk to each
 // other.  Team e owns sectors e, e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...
 //   tile member r : range tile (r + q) mod 32 (16 columns) of task q  -> the team's ONE 1 MiB slot
 //   row member r  : gates 16 r .. 16 r + 15 of every task (wave w: gates 16 r + 2 w, + 1), a4 .. a9
 // Hand-offs.  A task goes through the slot in two HALVES g = 0, 1 -- the gates with (gate mod 16) in
 // [8 g, 8 g + 8), which is exactly what k1-group g of a tile produces (see below); gate -> slot row
-// (gate >> 4) * 8 + (gate & 7).  Each half has its own pair of counters:
-//   stored[g] : tile members count a task's half once its stores have drained; row members wait for 32
-//   loaded[g] : row members count once their 8 rows of the half are in registers; tile members wait
-//               for 32 before they put the next half into the slot
+// (gate >> 4) * 8 + (gate & 7).  Each half has its own pair of flag arrays:
+//   stored[g] : a tile member publishes "half g of q tasks stored" once its stores have drained; a row
+//               member waits until all 32 tile members have published the task it wants
+//   loaded[g] : a row member publishes once its 8 rows of the half are in registers; a tile member waits for
+//               all 32 before it puts the next half into the slot
 // A tile member stores half 0 in the middle of a tile and half 1 at its end; while the rows of one
 // half are loaded and transformed the tile members compute the other half.  (Two slots, one per half,
 // give each hand-over a whole task of slack -- and were no faster: 2 MiB rewritten per XCD do not stay
 // in the 4 MiB L2 beside the streaming input, see the look in the tile loop.)  Store drains
 // are waited for where they cost nothing: half 0 behind the next tile's requests (counted s_waitcnt:
 // the loads are younger than the stores), half 1 behind the next tile's stage 1.
-// Each counter exists in 32 replicas on lines of their own; a signalling workgroup adds to all 32
-// with ONE wave instruction and every waiter polls only ITS replica (32 workgroups polling one line
-// took 2.7 us to notice a count in round 1).  Counters are monotonic over tasks.  All of this stays
-// inside one XCD, whose L2 is the point of coherence for its own CUs: tiles are stored with plain
-// stores (the lines stay in that L2) and drained with s_waitcnt vmcnt(0) before the count; rows and
-// counters are read with loads that miss the reader's L1 (sc1).  The input is read non-temporally so
-// that it does not push the slot out of the L2.  Counters are polled with scalar loads (glc): scalar
-// memory has its own path and counter, a vector poll would queue behind the CU's tile requests.  Every
-// spin is bounded; a timeout or a team that
-// is not 32 + 32 is reported in FusedCtl::status and the engine falls back to the two-kernel path.
+// Every POLLER has a 128-byte line of its own per array; byte w of it belongs to writer w.  A writer
+// publishes with ONE wave instruction (lane i stores its sequence number, mod 256, into byte `rank` of
+// line i: plain stores, the lines stay in the L2), a poller reads its line with one scalar load behind an
+// s_dcache_inv (served by the L2; see l2_flag32 / l2_peek_flags for what the earlier forms cost).  All of
+// this stays inside one XCD, whose L2 is the point of coherence for its own CUs: tiles are stored with plain
+// stores (the lines stay in that L2) and drained with s_waitcnt vmcnt before the flag goes out; rows are
+// read with loads that miss the reader's L1 (sc1).  The input is read non-temporally so that it does not
+// push the slot out of the L2.  Every spin is bounded; a timeout or a team that is not 32 + 32 is reported
+// in FusedCtl::status and the engine falls back to the two-kernel path.
 //
 // Range FFT: exactly the arithmetic of range_pass_1024<16> (1024 = 16 x 8 x 8, same butterflies,
 // same twiddles, same order -> bit-identical results; the library is built with -ffp-contract=off
@@ -66,7 +66,13 @@ constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (ta
 constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the gates of ONE half
 constexpr size_t FUSED_TEAM_ELEMS = (size_t)FUSED_SLOT_ROWS * DP_N;   // float2 units: ONE slot[256][512] = 1 MiB per team
 
-struct FusedLine { unsigned w; unsigned pad[31]; };   // one counter per 128-byte line
+// One 128-byte line per POLLER; byte w of it is writer w's sequence number (tasks done, mod 256), written with a plain
+// byte store.  A poller wants all 32 bytes EQUAL to its target, and equality is the right test because a writer is
+// never AHEAD of a poller's target: a tile member stores half g of task q+1 only after every row member has published
+// "half g of task q loaded" (one slot: the looks), and a row member loads half g of task q+1 only after every tile
+// member has published it.  So at the moment of a look a writer's byte is the target or the target minus one --
+// also across the wrap of the byte.  32 bytes are one s_load_dwordx8.
+struct FusedFlags { unsigned char b[FUSED_MEMBERS]; unsigned char pad[128 - FUSED_MEMBERS]; };
 struct FusedCtl {               // zeroed by the host once; every launch leaves it zeroed again (the teams' last workgroups)
     unsigned unused0;
     unsigned status;            // 0 ok; 1: a bounded spin gave up; 2: a team is not 32 + 32 workgroups.  Sticky: the host zeroes the block after a failure
@@ -76,8 +82,8 @@ struct FusedCtl {               // zeroed by the host once; every launch leaves 
     unsigned pad1[8];
     unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
     unsigned cu_block[8][256][2];            // blockIdx + 1 of the first and the second workgroup to arrive there
-    FusedLine stored[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: tile halves stored so far; polled by row member r only
-    FusedLine loaded[2][8][FUSED_MEMBERS];   // [half][xcc][replica r]: row sets loaded so far; polled by tile member r only
+    FusedFlags stored[2][8][FUSED_MEMBERS];  // [half][xcc][line of row member r]: byte t = tasks whose half tile member t has stored
+    FusedFlags loaded[2][8][FUSED_MEMBERS];  // [half][xcc][line of tile member t]: byte r = tasks whose half row member r has in registers
 };
 static_assert(sizeof(FusedCtl) % 16 == 0, "memset block is a multiple of 16 bytes");
 
@@ -120,37 +126,43 @@ __device__ __forceinline__ unsigned hw_cu_key()   // se, sh, cu of the CU this w
     return (v >> 8) & 0xff;
 }
 
-// Team counters are only ever touched by workgroups of ONE XCD, whose L2 performs every atomic:
-// additions are plain L2 atomics (workgroup scope, no sc1, the line stays in that L2).
-// One wave instruction, 32 lanes: lane r adds to replica r (line r of `lines`).  The lane offset is
-// recomputed at every call: kept across the task loop it is spilled, and the reload of a spilled
+// Notifications stay inside ONE XCD and inside its L2 (tools/hopbench.hip, profiles/r02/hopbench.log):
+//   * a writer publishes its sequence number with ONE wave instruction, lane i storing the byte into line i (the line of
+//     poller i): PLAIN stores, the lines stay in the L2.  A line that takes an atomic is written back and dropped -- the
+//     first form counted with L2 atomics on replicated counters, and every poll behind an update went out to memory;
+//   * a poller looks with s_dcache_inv + an ORDINARY scalar load: served by the L2.  A scalar load with glc is served by
+//     MEMORY, every time (hopbench: 650 bytes of FETCH_SIZE per notification and poller; the launch fetched 1.0 MB per
+//     sector with its input loads switched off) -- 0.73 us per notification on an idle chip against 0.43 us this way,
+//     and under load the difference is the fabric's queueing.  Scalar, because scalar memory has its own path and
+//     counter (lgkmcnt): a vector poll returns in order behind the polling wave's own tile requests, and the row
+//     workgroup's vector polls queue in the CU's memory pipeline with the tile workgroup's requests (measured slower).
+// The lane offset is recomputed at every call: kept across the task loop it is spilled, and the reload of a spilled
 // address waits (vmcnt, in order) for every request in flight -- the whole next tile.
-__device__ __forceinline__ void l2_count32(FusedLine *lines /* wave-uniform */, int l)
+__device__ __forceinline__ void l2_flag32(FusedFlags *lines /* wave-uniform */, int l, int rank, unsigned seq)
 {
     asm volatile("" : "+v"(l));
-    if (l < FUSED_MEMBERS) __hip_atomic_fetch_add(&lines[l].w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (l < FUSED_MEMBERS) __hip_atomic_store(&lines[l].b[rank], (unsigned char)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// A look at a team counter: a SCALAR load with glc (misses the scalar cache, served by the L2).
-// Scalar memory operations have their own counter (lgkmcnt): a vector poll -- load or atomic --
-// returns in order behind the polling wave's own tile requests, i.e. after the HBM latency of a
-// whole tile, and was measured 0.1 us per sector slower even where nothing is in front of it.
-__device__ __forceinline__ unsigned l2_peek(unsigned *p /* wave-uniform */)
+// 0 when all 32 bytes of the line equal the low byte of `seq`
+typedef unsigned v8u __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned l2_peek_flags(const FusedFlags *line /* wave-uniform */, unsigned seq)
 {
-    unsigned v;
-    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    return v;
+    v8u a;
+    asm volatile("s_dcache_inv\n\ts_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(a) : "s"(line) : "memory");
+    const unsigned pat = (seq & 0xffu) * 0x01010101u;
+    return ((a[0] ^ pat) | (a[1] ^ pat)) | ((a[2] ^ pat) | (a[3] ^ pat)) | ((a[4] ^ pat) | (a[5] ^ pat)) | ((a[6] ^ pat) | (a[7] ^ pat));
 }
 
 // control words in LDS: address space 3 spelled out, because hipcc does not infer it for volatile
 // accesses and would emit flat instructions with sc0 sc1 for them
 typedef __attribute__((address_space(3))) volatile int lds_word;
 
-// thread 0 of the workgroup: wait until *p >= target; false = gave up (status set)
-__device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *status)
+// a row wave: wait until every tile member has published `seq`; false = gave up (status set)
+__device__ __forceinline__ bool spin_flags(const FusedFlags *line, unsigned seq, unsigned *status)
 {
 #pragma unroll 1
     for (unsigned spins = 0; spins < (1u << 22); spins++) {
-        if (l2_peek(p) >= target) return true;
+        if (l2_peek_flags(line, seq) == 0) return true;
         if ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -162,26 +174,38 @@ __device__ __forceinline__ bool spin_ge(unsigned *p, unsigned target, unsigned *
 // tile loop 14 spilled registers); a wave that gave up remembers it (`failed`, wave-uniform), stops
 // waiting and runs on -- the launch is reported as failed through `status` and its output discarded
 // skip (wave-uniform): a wave that has nothing to wait for passes straight through, without a branch
-__device__ __forceinline__ void spin_ge_sticky(unsigned *p, unsigned target, int &failed, bool skip = false)
+__device__ __forceinline__ void spin_flags_sticky(const FusedFlags *line, unsigned seq, int &failed, bool skip = false)
 {
     // the whole bounded loop is ONE asm statement: hipcc sees no control flow, so the registers
-    // that are live across it (a tile's worth) are not split around a loop and spilled
-    unsigned v, budget = failed ? 1u : (1u << 22);
-    const unsigned have = __builtin_amdgcn_readfirstlane(skip ? 0xffffffffu : 0u);
-    asm volatile("s_cmp_ge_u32 %4, %3\n\t"
+    // that are live across it (a tile's worth) are not split around a loop and spilled.  The eight
+    // dwords of the line land in s[92:99], above what the kernel otherwise uses.
+    unsigned budget = __builtin_amdgcn_readfirstlane(failed ? 1u : (1u << 22));
+    const unsigned have = __builtin_amdgcn_readfirstlane(skip ? 0xffffffffu : 0u);   // 0: look, else: pass
+    const unsigned p32 = __builtin_amdgcn_readfirstlane((seq & 0xffu) * 0x01010101u);
+    const unsigned long long pat = ((unsigned long long)p32 << 32) | p32;
+    asm volatile("s_cmp_lg_u32 %[have], 0\n\t"
                  "s_cbranch_scc1 wrp_done%=\n"
                  "wrp_spin%=:\n\t"
-                 "s_load_dword %0, %2, 0x0 glc\n\t"
+                 "s_dcache_inv\n\t"
+                 "s_load_dwordx8 s[92:99], %[p], 0x0\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
-                 "s_cmp_ge_u32 %0, %3\n\t"
+                 "s_xor_b64 s[92:93], s[92:93], %[pat]\n\t"
+                 "s_xor_b64 s[94:95], s[94:95], %[pat]\n\t"
+                 "s_xor_b64 s[96:97], s[96:97], %[pat]\n\t"
+                 "s_xor_b64 s[98:99], s[98:99], %[pat]\n\t"
+                 "s_or_b64 s[92:93], s[92:93], s[94:95]\n\t"
+                 "s_or_b64 s[96:97], s[96:97], s[98:99]\n\t"
+                 "s_or_b64 s[92:93], s[92:93], s[96:97]\n\t"
+                 "s_cmp_eq_u64 s[92:93], 0\n\t"
                  "s_cbranch_scc1 wrp_done%=\n\t"
-                 "s_sub_u32 %1, %1, 1\n\t"
-                 "s_cmp_eq_u32 %1, 0\n\t"
+                 "s_sub_u32 %[budget], %[budget], 1\n\t"
+                 "s_cmp_eq_u32 %[budget], 0\n\t"
                  "s_cbranch_scc1 wrp_done%=\n\t"
                  "s_sleep 1\n\t"
                  "s_branch wrp_spin%=\n"
                  "wrp_done%=:"
-                 : "=&s"(v), "+s"(budget) : "s"(p), "s"(target), "s"(have) : "memory", "scc");
+                 : [budget] "+s"(budget) : [p] "s"(line), [pat] "s"(pat), [have] "s"(have)
+                 : "memory", "scc", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
     failed |= budget == 0;   // straight-line code here; the caller reports `failed` once, after its loop
 }
 
@@ -414,9 +438,9 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
     for (int g = 0; g < 2; g++) {
         z = reinterpret_cast<uint4 *>(ctl->stored[g][xcc]);
-        for (int e = tid; e < (int)(FUSED_MEMBERS * sizeof(FusedLine) / 16); e += FUSED_THREADS) z[e] = zero;
+        for (int e = tid; e < (int)(FUSED_MEMBERS * sizeof(FusedFlags) / 16); e += FUSED_THREADS) z[e] = zero;
         z = reinterpret_cast<uint4 *>(ctl->loaded[g][xcc]);
-        for (int e = tid; e < (int)(FUSED_MEMBERS * sizeof(FusedLine) / 16); e += FUSED_THREADS) z[e] = zero;
+        for (int e = tid; e < (int)(FUSED_MEMBERS * sizeof(FusedFlags) / 16); e += FUSED_THREADS) z[e] = zero;
     }
     z = reinterpret_cast<uint4 *>(ctl->cu_arrivals[xcc]);
     for (int e = tid; e < 256 / 4; e += FUSED_THREADS) z[e] = zero;
@@ -498,7 +522,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         int *s_arrived = reinterpret_cast<int *>(smem + T::OFF_CTL + 56);   // two arrival counters (the row kind uses +48, +52)
         if (tid < 2) s_arrived[tid] = 0;
         __syncthreads();
-        unsigned *my_loaded0 = &ctl->loaded[0][xcc][rank].w, *my_loaded1 = &ctl->loaded[1][xcc][rank].w;
+        const FusedFlags *my_loaded0 = &ctl->loaded[0][xcc][rank], *my_loaded1 = &ctl->loaded[1][xcc][rank];
         int failed = 0;
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
@@ -512,7 +536,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int last = 0;
             if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
-            if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->stored[1][xcc], l);
+            if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
             fused_stage1<1>(smem, v, wdv, gc);
             __syncthreads();                    // A1: group 0 is in the image
             stamp(q, 1);
@@ -530,7 +554,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             // row loads is what every tile member waited for); 1 MiB does -- write-backs 3.5 -> 0.5 MB per sector at
             // the same speed.  The look comes as late as it can: one wave, in front of the barrier behind which the
             // stores go out.
-            spin_ge_sticky(my_loaded1, (unsigned)(FUSED_MEMBERS * q), failed, w != 0);
+            spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_store(mid, tile_col(q), 0, o);
             // BEHIND the stores, so that a counted wait can tell them apart
@@ -541,14 +565,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             // ... and counted by the last wave to get here, without waiting for the barrier
             last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
-            if (__builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->stored[0][xcc], l);
+            if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
             stamp(q, 6);
             __syncthreads();                    // A3: group 1 is in the image
             stamp(q, 3);
             fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
             fused_stage3(smem, o);
-            spin_ge_sticky(my_loaded0, (unsigned)(FUSED_MEMBERS * (q + 1)), failed, w != 0);
+            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             stamp(q, 7);
             __syncthreads();                    // A4: image free for the next stage 1; the slot is free for half 1 (the rows have half 0 of THIS task)
             fused_store(mid, tile_col(q), 1, o);
@@ -556,7 +580,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tasks > 0 && w == 0) l2_count32(ctl->stored[1][xcc], l);
+        if (tasks > 0 && w == 0) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)tasks);
         if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flush_stamps();
         fused_leave(ctl, host_status, xcc, s_ctl);
@@ -575,12 +599,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         const DumpPtrs nodump{};
         const int g = w >> 2;                                  // this wave's half
         const int g0 = rank * 16 + 8 * g + 2 * (w & 3);        // its gates g0, g0 + 1
-        unsigned *my_stored = &ctl->stored[g][xcc][rank].w;
+        const FusedFlags *my_stored = &ctl->stored[g][xcc][rank];
         float s_hh0 = 0.f, s_hh1 = 0.f;     // HH row sums of this wave's gates, waiting for the VV task
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             stamp(q, 0);
-            if (!spin_ge(my_stored, (unsigned)(FUSED_MEMBERS * (q + 1)), &ctl->status)) break;   // status is set: the launch is void
+            if (!spin_flags(my_stored, (unsigned)(q + 1), &ctl->status)) break;   // status is set: the launch is void
             stamp(q, 1);
             cf x0[8], x1[8];
             const int r0 = rank * 8 + 2 * (w & 3);                 // slot rows of the gates g0, g0 + 1 (either half)
@@ -589,7 +613,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
             int last = 0;
             if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
-            if (__builtin_amdgcn_readfirstlane(last)) l2_count32(ctl->loaded[g][xcc], l);
+            if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
             stamp(q, 2);
             const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g0, false, nodump);
             const float s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump);
