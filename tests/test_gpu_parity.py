@@ -261,6 +261,15 @@ def test_vh_plane_is_carried_but_ignored(wrp, sectors):
         iq3[0, :2] = sectors[1]
         iq3[0, 2] = np.nan
         assert np.array_equal(e3.process_host(iq3), e2.process_host(sectors[1][None]))
+        # the same through the fused launch (batches of >= 8 sectors): shape A3 of SURVEY 8(d), the reference-faithful
+        # 12 MiB-per-sector block; the tile workgroups step over the VH plane
+        count = 9
+        b2 = np.stack([sectors[k % 3] * np.float32(1 + 0.5 * k) for k in range(count)])
+        b3 = np.full((count, 3, M, N), np.nan, np.complex64)
+        b3[:, :2] = b2
+        got3 = e3.process_host(b3)
+        assert np.array_equal(got3.view(np.uint32), e2.process_host(b2).view(np.uint32))
+        assert e3.lib.wrp_last_hip_error(e3.handle) == b""          # the fused launch ran, no fallback
 
 
 def test_special_values_compare_by_class(wrp, oracle, sectors):
