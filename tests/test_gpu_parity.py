@@ -159,6 +159,26 @@ def test_fused_launch_is_bit_identical_to_two_kernel_path(wrp, oracle, sectors):
         assert np.array_equal(ef.process_host(batch[:3]), b[:3])
 
 
+def test_fused_launch_beyond_256_tasks_per_team(wrp, sectors):
+    """The hand-over flags of the fused launch are sequence numbers mod 256 (one byte per writer).  A launch over 1040
+    sectors gives every XCD team 260 channel-tasks: the bytes wrap, and every sector must still come out bit for bit
+    as in a small batch."""
+    import torch
+    S = 1040
+    pool = np.stack([sectors[k % 3] * np.float32(1 + 0.25 * k) for k in range(4)])
+    d_pool = torch.from_numpy(pool.view(np.float32).reshape(4, -1)).cuda()
+    d_iq = d_pool[torch.arange(S, device="cuda") % 4].contiguous()
+    d_out = torch.zeros(S, M // 2, 2, device="cuda")
+    with wrp.Engine(device=0, n_slots=1, max_batch=S) as e, wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
+        e.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
+        e.check()
+        torch.cuda.synchronize()
+        assert e.lib.wrp_last_hip_error(e.handle) == b""          # one fused launch, no fallback
+        want = e2.process_host(pool)
+    got = d_out.cpu().numpy().view(np.uint32).reshape(S // 4, 4, M // 2, 2)
+    assert np.array_equal(got, np.broadcast_to(want.view(np.uint32), got.shape))
+
+
 def test_fused_intermediate_equals_the_dumped_range_fft(wrp, sectors):
     """The stage dumps come from the two-kernel form; the fused launch keeps its intermediate in the XCDs' L2.
     Its hand-over slots after a launch over 8 sectors (one per XCD team) must hold, bit for bit, what went through
