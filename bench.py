@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("WRP_MAX_BATCH", "0")))
     ap.add_argument("--shape", choices=["A", "B"], default="A",
                     help="A: the 00iq.altb shape 1024 x 512 (BASELINE metric); B: configs[4]'s 2048 range gates x 128 pulses")
+    ap.add_argument("--settle", type=float, default=SETTLE_S,
+                    help="seconds of untimed launches before the warm-up steps (profiling passes shorten it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -169,7 +171,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def settle(seconds=SETTLE_S):
+    def settle(seconds=None):
+        seconds = args.settle if seconds is None else seconds
         # The GPU has idled while the host prepared the input (or checked results): its clocks are down and the first
         # launches run slower.  Untimed launches for a fixed wall time bring it to its working point, whatever W is
         # (with --steps 20 --warmup 5 the same binary otherwise reads 4-5 % lower than with the defaults).
@@ -220,13 +223,12 @@ def main():
     # records a fingerprint of csrc/, include/ and the compiler flags: anything else reads null.
     traffic, traffic_note = None, "no traffic file for this build"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))
-        if args.shape != "A":
-            traffic_note = "no PMC run for this shape"
-        elif tj.get("fingerprint") != wrp_amd.source_fingerprint():
-            traffic_note = "profiles/%s/traffic.json was measured on other sources (fingerprint differs)" % PROFILE_ROUND
+        tname = "traffic.json" if args.shape == "A" else "traffic_%s.json" % args.shape
+        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, tname)))
+        if tj.get("fingerprint") != wrp_amd.source_fingerprint():
+            traffic_note = "profiles/%s/%s was measured on other sources (fingerprint differs)" % (PROFILE_ROUND, tname)
         elif tj.get("sectors_per_launch") != per_launch or tj.get("fused") != fused:
-            traffic_note = "profiles/%s/traffic.json was measured on another configuration" % PROFILE_ROUND
+            traffic_note = "profiles/%s/%s was measured on another configuration" % (PROFILE_ROUND, tname)
         else:
             traffic = round(tj["bytes_per_launch"])
             traffic_note = tj.get("source", "")
@@ -288,7 +290,7 @@ def main():
                                (f"shape B = BASELINE configs[4] (C=2, m=2048 range gates, n=128 pulses, fp32 complex), {S} sectors "
                                 f"per GPU per step, device-resident"), "sectors_per_step_per_gpu": S,
                    "parallelism": f"sector-sharded x{world}, no collective (gloo barrier + MAX only)",
-                   "launch": "fused" if fused else "two kernels", "untimed_settle_s": SETTLE_S},
+                   "launch": "fused" if fused else "two kernels", "untimed_settle_s": args.settle},
         "achieved_hbm_GBps": round(world * achieved, 1),
         "spot_check_vs_oracle": ok,
         "roofline": roofline,

@@ -13,6 +13,9 @@ echo "== bench B"; python3 bench.py --shape B --no-cpu-baseline > $OUT/bench_B.j
 echo "== kernel trace B"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_B -- python3 bench.py --shape B --no-cpu-baseline --no-end-to-end > $OUT/trace_B.log 2>&1
 echo "== PMC passes"; tools/profile_pmc.sh $OUT/pmc > $OUT/pmc.log 2>&1; tail -5 $OUT/pmc.log
 python3 tools/make_traffic.py $OUT/pmc/summary.txt 360 > $OUT/traffic.json && mkdir -p profiles/$R && cp $OUT/traffic.json profiles/$R/traffic.json
+echo "== traffic passes, shape B"; tools/profile_traffic.sh $OUT/pmc_B --shape B --steps 3 --warmup 2 --settle 0.01 --sectors 360 --no-cpu-baseline --no-end-to-end > $OUT/pmc_B.log 2>&1; tail -3 $OUT/pmc_B.log
+python3 tools/make_traffic.py $OUT/pmc_B/summary.txt 360 > $OUT/traffic_B.json && cp $OUT/traffic_B.json profiles/$R/traffic_B.json
+echo "== bench B with the traffic of this build"; python3 bench.py --shape B --no-cpu-baseline > $OUT/bench_B.json 2> $OUT/bench_B.err; tail -c 300 $OUT/bench_B.json
 echo "== bench A with the traffic of this build"; python3 bench.py > $OUT/bench_A.json 2> $OUT/bench_A.err; cat $OUT/bench_A.json
 # keep the merged directory small: the stats tables, not the raw traces
 find $OUT -name "*_kernel_trace.csv" -size +2M -delete
