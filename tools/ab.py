@@ -6,7 +6,7 @@ tune.py per build by +-1.5 %: too coarse for a 1 % change).
 
 Each library is dlopen'ed under its own path (two independent instances), gets one engine on device 0 and the same
 input; reports the median us/sector of each and the paired difference B - A with its standard error.
-Caveat, measured: two engines of the SAME build differ by up to 0.8 % here (standard error 0.05 %) -- where an engine's
+Caveat, measured: two engines of the SAME build differ by by 0.3 % (0.8 % with the counter protocol of mid round 2; standard error 0.05 %) -- where an engine's
 slots and control block land in memory matters that much; give the same library twice to see the floor on a box."""
 import argparse
 import ctypes as C
