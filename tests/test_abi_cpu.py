@@ -70,3 +70,18 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".c", ".cc")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"(from|import)\s+oracle|oracle/|liboracle|wro_", text), (dirpath, f)
+
+
+def test_source_fingerprint_ignores_comments_and_layout_only():
+    """bench.py reports the measured HBM traffic only when profiles/rNN/traffic.json carries the fingerprint of the code
+    it runs.  The fingerprint is over the code the compiler sees: a comment or re-indentation leaves it alone, a changed
+    token does not."""
+    from wrp_amd.binding import _code_only
+    a = "int f(int x)   // add one\n{\n    /* block\n       comment */ return x + 1;\n}\n"
+    b = "int f(int x)\n{\n  return x + 1;   // reworded\n}\n"
+    c = "int f(int x)\n{\n  return x + 2;\n}\n"
+    assert _code_only(a) == _code_only(b)
+    assert _code_only(a) != _code_only(c)
+    import wrp_amd
+    fp = wrp_amd.source_fingerprint()
+    assert len(fp) == 16 and fp == wrp_amd.source_fingerprint()
