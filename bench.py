@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 SETTLE_S = 0.3     # untimed launches before the W warm-up steps: the clocks reach their working point (see settle())
 
 
@@ -58,41 +58,85 @@ def host_cpus():
 
 
 def cpu_baseline_child(threads, budget_s, m=1024, n=512):
-    """Runs in a FRESH process whose OMP_NUM_THREADS was set before anything was imported."""
+    """Runs in a FRESH process whose OMP_* environment was set before anything was imported: three bounded samples."""
     import numpy as np
     from oracle import oracle as O
     O.build()
     iq = O.synthetic_sector(0, m, n)
     coef = O.hamming_coef(m, n, np.float32)
-    O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)            # warm-up
+    O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)            # warm-up (threads created, pages touched)
     t0 = time.perf_counter()
     O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)
     one = time.perf_counter() - t0
-    cnt = max(3, min(5000, int(budget_s / max(one, 1e-4))))
-    t0 = time.perf_counter()
-    for _ in range(cnt):
-        O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)
-    dt = time.perf_counter() - t0
-    print(json.dumps({"sectors": cnt, "seconds": dt}))
+    cnt = max(3, min(5000, int(budget_s / 3 / max(one, 1e-4))))
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(cnt):
+            O.sector(iq[0], iq[1], dtype=np.float32, coef=coef)
+        rates.append(cnt / (time.perf_counter() - t0))
+    print(json.dumps({"sectors": cnt, "rates": rates, "affinity": len(os.sched_getaffinity(0))}))
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except Exception:
+        return None
 
 
 def cpu_baseline(m=1024, n=512):
+    """the oracle's fp32 port on this host: 1 thread, 16 threads (the CPU share of a one-GPU box) and all
+    PHYSICAL cores this process may use; each figure is the median of three bounded samples taken in a fresh process
+    with OMP_PLACES=cores OMP_PROC_BIND=spread.  What the process was actually allowed (affinity mask, cgroup CPU quota)
+    is part of the record: a quota of 16 CPUs under a 256-CPU mask is what makes 'all cores' slower than 16 threads."""
+    import statistics
     logical, physical, model = host_cpus()
-    threads = min(logical, 16)          # 16 = the CPU share of a one-GPU box; stated in `sample`
+    quota = cgroup_cpu_quota()
 
     def run(t, budget):
-        env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PROC_BIND="close")
+        env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PLACES="cores", OMP_PROC_BIND="spread" if t > 1 else "close")
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(t), str(budget), str(m), str(n)],
                              env=env, capture_output=True, text=True, timeout=300)
         r = json.loads(out.stdout.strip().splitlines()[-1])
-        return r["sectors"] / r["seconds"], r
-    allc, ra = run(threads, 10.0)
-    one, r1 = run(1, 8.0)
-    return {"value": round(allc, 2), "unit": "sectors/s", "cores": threads, "kind": "port",
-            "one_thread": round(one, 2), "physical_cores": physical, "logical_cpus": logical, "cpu_model": model,
-            "sample": f"{ra['sectors']} sectors of the same shape on {threads} OpenMP threads ({ra['seconds']:.1f} s; "
-                      f"min(usable logical CPUs, 16)) and {r1['sectors']} sectors on 1 thread ({r1['seconds']:.1f} s); "
-                      f"oracle/radar_oracle.c fp32 port, each in a fresh process"}
+        return round(statistics.median(r["rates"]), 2), r
+    t16 = min(logical, 16)
+    runs = {}
+    for t, budget in ((1, 8.0), (t16, 8.0), (physical, 8.0)):
+        if t not in runs:
+            runs[t] = run(t, budget)
+    best_t = max(runs, key=lambda t: runs[t][0])
+    return {"value": runs[best_t][0], "unit": "sectors/s", "cores": best_t, "kind": "port",
+            "one_thread": runs[1][0], "threads_16": runs[t16][0], "all_physical_cores": runs[physical][0],
+            "physical_cores": physical, "logical_cpus_in_affinity_mask": logical, "cgroup_cpu_quota": quota, "cpu_model": model,
+            "samples_sectors_per_s": {str(t): [round(x, 2) for x in r["rates"]] for t, (_, r) in runs.items()},
+            "sample": "median of 3 samples of %s sectors of the same shape per thread count (1, %d, %d = physical cores in the mask), "
+                      "OMP_PLACES=cores OMP_PROC_BIND=spread, each thread count in a fresh process; `value` is the best of them; "
+                      "oracle/radar_oracle.c fp32 port" % ("/".join(str(r["sectors"]) for _, r in runs.values()), t16, physical)}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes with torch.distributed.run BEFORE this
+    process has touched a GPU, relay rank 0's JSON line and exit with the launcher's code."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()            # counts devices without initialising the GPU
+    if have < n:
+        sys.exit("bench.py: --gpus %d asked for, %d GPU(s) visible" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -113,6 +157,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import numpy as np
     import torch   # first: libwrp.so then binds to the HIP runtime torch already loaded
@@ -124,6 +172,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     ngpu = torch.cuda.device_count()
+    if ngpu < world and not os.environ.get("WRP_BENCH_OVERSUBSCRIBE"):
+        sys.exit("bench.py: %d ranks but %d GPU(s) visible (WRP_BENCH_OVERSUBSCRIBE=1 rehearses on a smaller box)" % (world, ngpu))
     dev_index = local_rank % max(ngpu, 1)     # one rank per GPU; wraps only when rehearsed on a smaller box
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
@@ -245,6 +295,25 @@ def main():
         roofline["range_pass_us_per_sector"] = round(ms_range * 1e3 / (iters * S), 3)
         roofline["doppler_pass_us_per_sector"] = round(ms_dopp * 1e3 / (iters * S), 3)
 
+    # BASELINE configs[1]: ONE sector, one stream -- pinned slot -> wrp_submit -> wrp_wait (H2D of the 8 MiB fp32 block, the
+    # range pass and the Doppler pass on 1 sector, D2H of 4 KiB); and the same sector already on the device (kernels only)
+    import statistics
+    eng.slot_array(0)[:] = pool[0]
+    lat, lat_dev = [], []
+    for k in range(210):
+        t0 = time.perf_counter()
+        eng.submit(0, 0, 0)
+        eng.wait(0)
+        lat.append((time.perf_counter() - t0) * 1e6)
+    for k in range(210):
+        t0 = time.perf_counter()
+        eng.process_batch_device(d_iq.data_ptr(), 1, d_out.data_ptr())
+        eng.check()
+        lat_dev.append((time.perf_counter() - t0) * 1e6)
+    single = {"submit_wait_pinned_us": round(statistics.median(lat[10:]), 1), "device_resident_us": round(statistics.median(lat_dev[10:]), 1),
+              "samples": 200, "what": "median wall time of one wrp_submit -> wrp_wait from a pinned slot (PCIe included) and of one "
+                                      "wrp_process_batch_device(1 sector) -> wrp_check on device-resident input; two-kernel path"}
+
     # end to end: every sector crosses PCIe.  Wire-format sector (12 B/sample, big-endian int16, 6 MiB) in
     # the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB, 4 slots cascading, all ranks at once.
     end_to_end = None
@@ -271,7 +340,28 @@ def main():
             dt = max_over_ranks(time.perf_counter() - t0)
         want = O.sector(pool[0][0], pool[0][1], dtype=np.float64)
         e_ok = bool(np.max(np.abs(eng.result(S - 1, 0)[1:] - want[1:])) < 1e-3)
+        # the same WITH the host's share: the C++ feeder (host/rpv2, one thread per GPU as rpv2.cu:665-683) copies every
+        # sector from a pageable buffer into its pinned slot before it submits it (6 MiB memcpy, as a socket delivers
+        # it), bound to the GPU's NUMA node; once with the feeder thread alone and once with 4 threads sharing the copy
+        with_fill = None
+        rpv2 = os.path.join(ROOT, "weather-radar-processing_amd", "host", "rpv2")
+        if args.shape == "A" and os.path.exists(rpv2):
+            import re
+            with_fill = {"unit": "sectors/s", "what": "rpv2 %d --device D --in synthetic:copy:T --bind-numa --out none: pageable -> pinned "
+                         "memcpy by T host thread(s) + H2D + decode + kernels + D2H per sector, all ranks at once" % SLOTS}
+            for T in (1, 4):
+                barrier()
+                out = subprocess.run([rpv2, str(SLOTS), "--device", str(dev_index), "--in", "synthetic:copy:%d" % T, "--bind-numa",
+                                      "--out", "none", "--scan", "%d,1" % S, "--sectors", str(3 * S)], capture_output=True, text=True, timeout=300)
+                mm = re.search(r"\(([0-9.]+) sectors/s end to end", out.stderr)
+                rate = float(mm.group(1)) if mm else 0.0
+                slowest = max_over_ranks(1.0 / rate if rate > 0 else float("inf"))          # every rank takes part
+                rate = world / slowest                                                       # the slowest rank's rate x ranks
+                with_fill["fill_threads_%d" % T] = round(rate, 1)
+                with_fill["numa_bound"] = "NUMA-bound" in out.stderr
+            barrier()
         end_to_end = {"value": round(world * S / dt, 1), "unit": "sectors/s", "slots": SLOTS, "sectors_per_gpu": S,
+                      "with_host_fill": with_fill,
                       "ingest": f"wire format, 12 B/sample big-endian int16 ({m * n * 12 / 2**20:g} MiB/sector), decoded on the GPU",
                       "h2d_GBps_per_gpu": round(S * m * n * 12 / dt / 1e9, 1), "spot_check_vs_oracle": e_ok,
                       "includes": "pinned H2D + decode + range/Doppler kernels + D2H per sector; host refill of the pinned "
@@ -293,6 +383,8 @@ def main():
                    "launch": "fused" if fused else "two kernels", "untimed_settle_s": args.settle},
         "achieved_hbm_GBps": round(world * achieved, 1),
         "spot_check_vs_oracle": ok,
+        "single_sector_latency_us": single["submit_wait_pinned_us"],
+        "single_sector": single,
         "roofline": roofline,
     }
     if end_to_end is not None:

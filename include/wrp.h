@@ -68,12 +68,10 @@ typedef struct {
 
 /* The m = 1024, n = 512 shape runs batches of >= WRP_FUSED_MIN_SECTORS sectors as ONE persistent
  * launch whose XCD teams hand the intermediate from the range FFT to the Doppler rows through
- * their L2 (csrc/wrp_fused.h); smaller batches, the slot cascade (wrp_submit) and all other
- * shapes run a range-pass kernel and a Doppler-pass kernel.  Both forms perform the same
+ * their L2 (csrc/wrp_fused.h); smaller batches, the slot cascade (wrp_submit) and the shapes without
+ * a fused kernel run a range-pass kernel and a Doppler-pass kernel.  Both forms perform the same
  * arithmetic and give bit-identical results.
- * WRP_FLAG_FUSED      : accepted for compatibility (the fused launch is the default);
  * WRP_FLAG_TWO_KERNELS: never use the fused launch (A/B measurements, parity tests). */
-#define WRP_FLAG_FUSED 0x100
 #define WRP_FLAG_TWO_KERNELS 0x800
 #define WRP_FUSED_MIN_SECTORS 8
 /* By default the two-kernel range pass is a fixed grid that walks the tiles and requests the
@@ -146,14 +144,19 @@ int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr);
  * stream: hipStream_t as void*, NULL = the engine's compute stream.  Asynchronous. */
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream);
 int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream);
-/* ONE batch is in flight per handle (the workspace is shared): a batch submitted on another
- * stream first waits, on the device, for the previous one.
- * The fused launch needs all its workgroups resident at once and says so when they are not
- * (e.g. another kernel occupies CUs): wrp_check waits for the handle's last batch and returns
- * WRP_ERR_HIP (text in wrp_last_hip_error) if a fused launch since the previous check gave up;
- * d_out of that batch is then undefined, the handle has switched to the two-kernel path and the
- * batch must be submitted again.  wrp_process_host and wrp_time_batch_device check by themselves. */
+/* Completion and ordering.  With a caller's stream the batch is ordered on that stream like any kernel.
+ * With stream = NULL the engine uses streams of its own and CONSECUTIVE BATCHES MAY OVERLAP (the
+ * workgroups of batch k + 1 move onto the CUs as the teams of batch k leave them): do not feed one
+ * batch's output into the next without a wrp_check in between.
+ * wrp_check waits for every batch submitted so far.  The fused launch needs all its workgroups resident
+ * at once and says so, within milliseconds, when they are not (e.g. another kernel occupies CUs); such a
+ * batch is REPEATED on the two-kernel path -- by wrp_check, or by the next wrp_process_batch_device once
+ * the launch has completed -- so d_out is valid once wrp_check has returned WRP_OK, and must not be
+ * consumed before that.  The handle then stays on the two kernels for 16 batches and tries the fused
+ * launch again; wrp_last_hip_error holds a note, wrp_fused_fallbacks the count of repeated batches.
+ * wrp_process_host and wrp_time_batch_device check by themselves. */
 int wrp_check(wrp_handle h);
+int wrp_fused_fallbacks(wrp_handle h);
 
 /* Synchronous convenience: host buffers in the same layouts (pageable or pinned). */
 int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *out_host);
@@ -194,6 +197,9 @@ size_t wrp_result_bytes(wrp_handle h);   /* (m/2)*2*4      */
  * 2*m*n*8 (HH and VV read once) + (m/2)*2*4 (result written once). */
 size_t wrp_algorithmic_bytes(wrp_handle h);
 const char *wrp_version(void);
+/* NUMA node of the host the GPU hangs on (sysfs numa_node of its PCI device), or -1 when unknown:
+ * the feeder thread of a GPU fills its pinned slots fastest from that node (host/rpv2.cpp --bind-numa). */
+int wrp_device_numa_node(int device);
 
 #ifdef __cplusplus
 }

@@ -207,8 +207,7 @@ def test_fused_intermediate_equals_the_dumped_range_fft(wrp, sectors):
 
 def test_fused_launch_through_the_device_entry_and_check(wrp, sectors):
     """wrp_process_batch_device is asynchronous: wrp_check reports a fused launch that gave up.  Here it
-    must report success, on the engine's stream and on a caller's stream, back to back (one batch in
-    flight per handle: the second waits for the first on the device)."""
+    must report success, on the engine's streams and on a caller's stream, back to back."""
     import torch
     count = 16
     batch = np.stack([sectors[k % 3] * np.float32(1 + k) for k in range(count)])
@@ -226,11 +225,13 @@ def test_fused_launch_through_the_device_entry_and_check(wrp, sectors):
     assert np.array_equal(d_b.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
-def test_fused_launch_that_cannot_form_its_teams_is_reported(wrp, sectors):
+def test_fused_launch_that_cannot_form_its_teams_is_repeated(wrp, sectors):
     """A fused launch whose workgroups are not all there (here: launched with half of them; in the field: another
-    kernel holding CUs) must say so instead of delivering garbage: the asynchronous entry reports it through
-    wrp_check, once, and the handle runs the two kernels from then on; the synchronous entry repeats the batch
-    by itself and returns the right answer."""
+    kernel holding CUs) must not deliver garbage.  It says so itself, within milliseconds (the team meeting has a
+    4 ms deadline in real time), and the engine repeats the batch on the two-kernel path at its next synchronisation
+    point: after wrp_check the output is right, the note and the count are there, the handle stays on the two kernels
+    for a while and then tries the fused launch again."""
+    import time
     import torch
     count = 12
     batch = np.stack([sectors[k % 3] * np.float32(1 + k) for k in range(count)])
@@ -240,17 +241,48 @@ def test_fused_launch_that_cannot_form_its_teams_is_reported(wrp, sectors):
         want = e2.process_host(batch)
     with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:
         e.process_batch_device(d_in.data_ptr(), count, d_out.data_ptr())
-        with pytest.raises(wrp.WrpError) as err:
-            e.check()
-        assert "32 tile + 32 row" in str(err.value)
-        e.check()                                                   # reported once
-        e.process_batch_device(d_in.data_ptr(), count, d_out.data_ptr())      # now the two kernels
+        t0 = time.perf_counter()
         e.check()
-        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        assert e.fused_fallbacks == 1
+        assert b"32 tile + 32 row" in e.lib.wrp_last_hip_error(e.handle)
+        assert dt < 0.25, dt                                        # it used to take a second to say "busy"
+        for k in range(16):                                         # the cool-down: two kernels, no new fallback
+            d_out.zero_()
+            e.process_batch_device(d_in.data_ptr(), count, d_out.data_ptr())
+        e.check()
+        assert e.fused_fallbacks == 1
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        d_out.zero_()
+        e.process_batch_device(d_in.data_ptr(), count, d_out.data_ptr())      # re-armed: tries (and, undersized, fails) again
+        e.check()
+        assert e.fused_fallbacks == 2
         assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
     with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:
         assert np.array_equal(e.process_host(batch).view(np.uint32), want.view(np.uint32))
         assert b"two-kernel path" in e.lib.wrp_last_hip_error(e.handle)
+
+
+def test_consecutive_fused_batches_overlap_and_stay_bit_identical(wrp, sectors):
+    """With stream = NULL the engine alternates between two lanes (control block + hand-over slots + stream each), so
+    the workgroups of batch k + 1 move onto the CUs while the last teams of batch k finish.  Many batches back to back,
+    different inputs and outputs, every one bit-identical to the two-kernel path; wrp_check waits for all of them."""
+    import torch
+    count = 24
+    batches = [np.stack([sectors[(k + j) % 3] * np.float32(1 + 0.5 * ((k + j) % 4)) for k in range(count)]) for j in range(3)]
+    d_in = [torch.from_numpy(b.view(np.float32)).cuda() for b in batches]
+    reps = 12
+    d_out = [torch.zeros(count, M // 2, 2, device="cuda") for _ in range(reps)]
+    with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
+        want = [e2.process_host(b) for b in batches]
+    with wrp.Engine(device=0, n_slots=1) as e:
+        for r in range(reps):
+            e.process_batch_device(d_in[r % 3].data_ptr(), count, d_out[r].data_ptr())
+        e.check()
+        assert e.fused_fallbacks == 0 and e.lib.wrp_last_hip_error(e.handle) == b""
+        for r in range(reps):
+            assert np.array_equal(d_out[r].cpu().numpy().view(np.uint32), want[r % 3].view(np.uint32)), r
 
 
 def test_wire_format_ingest_is_bit_identical_to_cpu_decode(wrp, oracle):

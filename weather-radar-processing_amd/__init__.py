@@ -11,7 +11,6 @@ needs libwrp.so and a GPU and raises :class:`WrpError` otherwise.
 from .binding import (  # noqa: F401
     Engine,
     FLAG_DEBUG_FUSED_UNDERSIZED,
-    FLAG_FUSED,
     FLAG_GENERIC_KERNELS,
     FLAG_ONE_TILE_PER_BLOCK,
     FLAG_TWO_KERNELS,

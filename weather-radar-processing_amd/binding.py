@@ -26,7 +26,7 @@ class WrpConfig(C.Structure):
     ]
 
 
-FLAG_FUSED, FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_DEBUG_FUSED_UNDERSIZED, FLAG_GENERIC_KERNELS = 0x100, 0x400, 0x800, 0x4000, 0x8000
+FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_DEBUG_FUSED_UNDERSIZED, FLAG_GENERIC_KERNELS = 0x400, 0x800, 0x4000, 0x8000
 FUSED_MIN_SECTORS = 8
 
 STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7}
@@ -120,6 +120,7 @@ def load_library():
     lib.wrp_process_batch_device.argtypes = [vp, vp, i, vp, vp]
     lib.wrp_process_host.argtypes = [vp, vp, i, vp]
     lib.wrp_check.argtypes = [vp]
+    lib.wrp_fused_fallbacks.argtypes = [vp]
     lib.wrp_debug_fused_mid.argtypes = [vp, vp, i, vp, vp, C.c_size_t]
     lib.wrp_dump_stage.argtypes = [vp, i, i, i, vp]
     lib.wrp_time_batch_device.argtypes = [vp, vp, i, vp, i, fp, fp, fp]
@@ -242,8 +243,12 @@ class Engine:
                     "wrp_process_batch_device")
 
     def check(self):
-        """Wait for the last batch; raises if a fused launch since the previous check gave up."""
+        """Wait for every batch submitted so far (a fused launch that gave up is repeated on the two-kernel path here)."""
         self._check(self.lib.wrp_check(self._h), "wrp_check")
+
+    @property
+    def fused_fallbacks(self):
+        return self.lib.wrp_fused_fallbacks(self._h)
 
     def time_batch_device(self, d_iq_ptr, n_sectors, d_out_ptr, iters, per_kernel=False):
         """HIP-event timing on the engine's own stream -> (ms_total, ms_range, ms_doppler)."""

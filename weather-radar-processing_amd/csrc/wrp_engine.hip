@@ -1,13 +1,16 @@
-// wrp_engine.hip -- host side of libwrp.so: the C ABI of include/wrp.h on top of the two
-// gfx950 kernels in wrp_kernels.h.  Mirrors rpv2.cu's generate_constants / prepare_arys /
+// wrp_engine.hip -- host side of libwrp.so: the C ABI of include/wrp.h on top of the gfx950 kernels of
+// wrp_fused.h (one persistent launch per batch, the default), wrp_kernels.h / wrp_shape_b.h (range pass +
+// Doppler pass) and wrp_generic.h (any other power-of-two shape).  Mirrors rpv2.cu's generate_constants / prepare_arys /
 // initialize_streams / copy_matrix_to_device / perform_stage_1..3 / copy_result_to_host
 // (rpv2.cu:283-618) without its per-launch cudaDeviceSynchronize (rpv2.cu:422-569).
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -35,6 +38,19 @@ struct Slot {
     bool loaded = false;      // d_iq holds an uploaded sector
 };
 
+constexpr int WRP_RING = 64;            // fused batches that may be outstanding (status words, events)
+constexpr int WRP_FUSED_COOLDOWN = 16;  // batches on the two-kernel path after a fused launch that gave up
+
+struct FusedLane {
+    hipStream_t stream = nullptr;       // used when the caller passes no stream
+    wrp::FusedCtl *d_ctl = nullptr;
+    float2 *d_pool = nullptr;           // per XCD team: ONE hand-over slot of 1 MiB
+    hipEvent_t done = nullptr;          // the lane's last launch: the next one on this lane waits for it (workspace)
+    bool used = false;
+    bool ctl_dirty = true;              // memset before the next launch (first launch, after a failure)
+};
+struct FusedBatch { const float2 *in; int n; float *out; int slot; int lane; };
+
 } // namespace
 
 struct wrp_engine {
@@ -53,16 +69,23 @@ struct wrp_engine {
     bool tuned_b = false;     // m = 2048, n = 128 (BASELINE configs[4]): wrp_shape_b.h; its stage dumps come from wrp_generic.h
     bool persist = false;     // range pass as a fixed grid walking the tiles with prefetch
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
-    // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors
-    bool fused = false;
+    // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors.  Two LANES, each with its own
+    // control block, hand-over slots and stream: consecutive batches alternate between them, so the workgroups of batch
+    // k + 1 move onto the CUs as the teams of batch k leave them (a launch costs ~60 us beyond its sectors: team
+    // meeting, first tile, the rows of the last task, teams that finish early -- all of it now under the other lane).
+    bool fused = false;             // the shape and the flags allow the fused launch
+    bool fused_armed = false;       // ... and it is in use (false for WRP_FUSED_COOLDOWN batches after one that gave up)
+    int fused_cooldown = 0;
+    int fused_fallbacks = 0;        // batches that were repeated on the two-kernel path
     int n_cus = 0;
-    wrp::FusedCtl *d_ctl = nullptr;
-    float2 *d_mid_pool = nullptr;   // per XCD team: ONE mid[m/2][n]
-    unsigned *h_status = nullptr;   // pinned + mapped: word k % 64 is written by fused launch k itself, only when it failed
+    FusedLane lanes[2];
+    int next_lane = 0;
+    hipEvent_t ev_ring[WRP_RING] = {};   // completion of fused batch `slot`
+    unsigned *h_status = nullptr;   // pinned + mapped: word `slot` is written by the fused launch itself, only when it failed
     unsigned *d_status = nullptr;   // the same words as the device sees them
-    bool ctl_dirty = true;          // the control block needs a memset before the next fused launch (first launch, after a failure)
-    int fused_launches = 0;         // launches whose status has not been looked at yet
-    // batch workspace; one batch in flight per handle: the next batch's stream waits for ev_batch
+    int ring_next = 0;
+    std::deque<FusedBatch> outstanding;   // fused batches whose status word has not been looked at yet, oldest first
+    // two-kernel workspace; one such batch in flight per handle: the next one's stream waits for ev_batch
     hipStream_t stream = nullptr;
     hipEvent_t ev_batch = nullptr;
     bool batch_pending = false;
@@ -235,22 +258,22 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
 }
 
 // one persistent launch for the whole batch: XCD teams keep the intermediate in their L2 (wrp_fused.h)
-int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, hipStream_t st,
+int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_sectors, float *d_out, hipStream_t st, int slot,
                  unsigned long long *d_stamps = nullptr)
 {
     const wrp_config &c = h->cfg;
     // a successful launch leaves the control block zeroed (fused_leave): no memset node in front of the next one
-    if (h->ctl_dirty) {
-        HIP_TRY(h, hipMemsetAsync(h->d_ctl, 0, sizeof(wrp::FusedCtl), st));
-        h->ctl_dirty = false;
+    if (lane.ctl_dirty) {
+        HIP_TRY(h, hipMemsetAsync(lane.d_ctl, 0, sizeof(wrp::FusedCtl), st));
+        lane.ctl_dirty = false;
     }
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
     // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
 #define WRP_FUSED(TAPS, STAMPS)                                                                                       \
     hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
-                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, h->d_mid_pool, h->d_ctl, rc, h->d_tw_n_arr, n_sectors, \
-                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + h->fused_launches % 64, d_stamps)
+                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps)
     if (d_stamps) {
         if (h->taps_pad == 7) WRP_FUSED(7, true); else WRP_FUSED(9, true);
     } else {
@@ -258,26 +281,95 @@ int launch_fused(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out,
     }
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
-    // a launch that fails says so in its own pinned word (written from the kernel); looked at by check_fused()
-    h->fused_launches++;
     return WRP_OK;
 }
 
-// Outcome of the fused launches issued so far whose stream work has completed (the caller has
-// synchronised, or we do).  A failure (bounded spin gave up, or the CUs did not host 32 + 32
-// workgroups per XCD) switches the handle to the two-kernel path and is reported ONCE.
-int check_fused(wrp_engine *h)
+int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
+                 hipStream_t st, const wrp::DumpPtrs *dump);
+size_t sector_elems(const wrp_config &c);
+
+// the two-kernel path over a whole batch, in chunks of max_batch sectors, on stream st (shared workspace d_mid: the
+// stream first waits for the previous two-kernel batch)
+int launch_two_kernel_batch(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t st)
 {
-    if (h->fused_launches == 0) return WRP_OK;
-    unsigned bad = 0;
-    for (int k = 0; k < 64; k++) { bad |= h->h_status[k]; h->h_status[k] = 0; }
-    h->fused_launches = 0;
-    if (!bad) return WRP_OK;
-    h->fused = false;
-    h->ctl_dirty = true;
-    h->hip_err = (bad & 2) ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; handle switched to the two-kernel path"
-                           : "fused launch: a bounded wait gave up (workgroups not co-resident?); handle switched to the two-kernel path";
-    return WRP_ERR_HIP;
+    const wrp_config &c = h->cfg;
+    if (h->batch_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_batch, 0));
+    for (int s0 = 0; s0 < n_sectors; s0 += h->max_batch) {
+        const int cnt = std::min(h->max_batch, n_sectors - s0);
+        const int rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
+        if (rc != WRP_OK) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_batch, st));
+    h->batch_pending = true;
+    return WRP_OK;
+}
+
+// A fused launch that gave up (bounded wait, or the CUs did not host 32 tile + 32 row workgroups per XCD: another kernel
+// on the GPU) has said so in its own pinned status word.  Its output is void: the batch is computed again, here and
+// synchronously, by the two kernels; the handle stays on them for WRP_FUSED_COOLDOWN batches and then tries again.
+int redo_batch(wrp_engine *h, const FusedBatch &b, unsigned status)
+{
+    h->fused_armed = false;
+    h->fused_cooldown = WRP_FUSED_COOLDOWN;
+    h->fused_fallbacks++;
+    h->lanes[b.lane].ctl_dirty = true;
+    const std::string note = (status & 2)
+        ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; batch repeated on the two-kernel path"
+        : "fused launch: a bounded wait gave up (workgroups not co-resident?); batch repeated on the two-kernel path";
+    int rc = launch_two_kernel_batch(h, b.in, b.n, b.out, h->stream);
+    if (rc != WRP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->batch_pending = false;
+    h->hip_err = note;
+    return WRP_OK;
+}
+
+// Look at the status words of the fused batches that have completed (block = false) or of all of them, waiting for each
+// (block = true); repeat the ones that gave up.  Called from every entry that touches the batch path.
+int reap_fused(wrp_engine *h, bool block, size_t leave = 0)
+{
+    while (h->outstanding.size() > leave) {
+        const FusedBatch b = h->outstanding.front();
+        if (block) {
+            HIP_TRY(h, hipEventSynchronize(h->ev_ring[b.slot]));
+        } else {
+            const hipError_t q = hipEventQuery(h->ev_ring[b.slot]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+            HIP_TRY(h, q);
+        }
+        h->outstanding.pop_front();
+        const unsigned st = h->h_status[b.slot];
+        h->h_status[b.slot] = 0;
+        if (st) {
+            const int rc = redo_batch(h, b, st);
+            if (rc != WRP_OK) return rc;
+        }
+    }
+    return WRP_OK;
+}
+
+// fused launch of one batch on the next lane; st = the caller's stream or nullptr (the lane's own)
+int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream)
+{
+    if (h->outstanding.size() >= (size_t)WRP_RING) {
+        const int rc = reap_fused(h, true, WRP_RING - 1);
+        if (rc != WRP_OK) return rc;
+        if (!h->fused_armed) return launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? stream : h->stream);
+    }
+    const int li = h->next_lane;
+    h->next_lane ^= 1;
+    FusedLane &lane = h->lanes[li];
+    hipStream_t st = stream ? stream : lane.stream;
+    if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // the lane's control block and slots are free again
+    const int slot = h->ring_next;
+    h->ring_next = (h->ring_next + 1) % WRP_RING;
+    const int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot);
+    if (rc != WRP_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_ring[slot], st));
+    HIP_TRY(h, hipEventRecord(lane.done, st));
+    lane.used = true;
+    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, li});
+    return WRP_OK;
 }
 
 int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
@@ -296,6 +388,8 @@ int destroy_impl(wrp_engine *h)
 {
     if (!h) return WRP_OK;
     (void)hipSetDevice(h->device);
+    for (const auto &b : h->outstanding) (void)hipEventSynchronize(h->ev_ring[b.slot]);   // also those on caller streams
+    h->outstanding.clear();
     for (auto &s : h->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -312,8 +406,13 @@ int destroy_impl(wrp_engine *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->d_mid) (void)hipFree(h->d_mid);
-    if (h->d_ctl) (void)hipFree(h->d_ctl);
-    if (h->d_mid_pool) (void)hipFree(h->d_mid_pool);
+    for (auto &lane : h->lanes) {
+        if (lane.stream) { (void)hipStreamSynchronize(lane.stream); (void)hipStreamDestroy(lane.stream); }
+        if (lane.done) (void)hipEventDestroy(lane.done);
+        if (lane.d_ctl) (void)hipFree(lane.d_ctl);
+        if (lane.d_pool) (void)hipFree(lane.d_pool);
+    }
+    for (auto &e : h->ev_ring) if (e) (void)hipEventDestroy(e);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->d_dump) (void)hipFree(h->d_dump);
     if (h->h_result) (void)hipHostFree(h->h_result);
@@ -338,6 +437,7 @@ int create_impl(wrp_engine *h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
     // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
     h->fused = h->tuned && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
+    h->fused_armed = h->fused;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
     if ((c.flags & 0xff) == 0) h->range_tcols = h->persist ? 16 : 8;   // best measured tile for each form
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024_persistent<8>),
@@ -359,10 +459,15 @@ int create_impl(wrp_engine *h)
     WRP_FUSED_ATTR(7, false); WRP_FUSED_ATTR(9, false);
     WRP_FUSED_ATTR(7, true);  WRP_FUSED_ATTR(9, true);
 #undef WRP_FUSED_ATTR
-    HIP_TRY(h, hipMalloc(&h->d_ctl, sizeof(wrp::FusedCtl)));
-    HIP_TRY(h, hipMalloc(&h->d_mid_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8));
-    HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * 64, hipHostMallocMapped));
-    std::memset(h->h_status, 0, sizeof(unsigned) * 64);
+    for (auto &lane : h->lanes) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+        HIP_TRY(h, hipMalloc(&lane.d_ctl, sizeof(wrp::FusedCtl)));
+        HIP_TRY(h, hipMalloc(&lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
+    }
+    for (auto &e : h->ev_ring) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * WRP_RING, hipHostMallocMapped));
+    std::memset(h->h_status, 0, sizeof(unsigned) * WRP_RING);
     HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_status, h->h_status, 0));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_1024<16, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTile<16>::LDS_BYTES));
@@ -448,8 +553,8 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_FUSED | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED | WRP_FLAG_GENERIC_KERNELS)) != 0 ||
-        ((cfg->flags & WRP_FLAG_FUSED) && (cfg->flags & WRP_FLAG_TWO_KERNELS)) || ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
+        (cfg->flags & ~(0xff | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED | WRP_FLAG_GENERIC_KERNELS)) != 0 ||
+        ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -574,36 +679,31 @@ int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, floa
     if (!h || !d_iq || !d_out || n_sectors < 0) return WRP_ERR_INVALID;
     if (n_sectors == 0) return WRP_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    const wrp_config &c = h->cfg;
     const float2 *in = (const float2 *)d_iq;
-    // ONE batch in flight per handle: the workspace (intermediate, team buffers, control block) is
-    // shared, so a batch on another stream first waits for the previous batch (free on one stream)
-    if (h->batch_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_batch, 0));
-    int rc = WRP_OK;
-    if (h->fused && n_sectors >= WRP_FUSED_MIN_SECTORS) {
-        rc = launch_fused(h, in, n_sectors, d_out, st);
-    } else {
-        for (int s0 = 0; s0 < n_sectors && rc == WRP_OK; s0 += h->max_batch) {
-            const int cnt = std::min(h->max_batch, n_sectors - s0);
-            rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid,
-                              d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
-        }
-    }
+    // every entry of the batch path looks at the fused launches that have completed since the last look
+    int rc = reap_fused(h, false);
     if (rc != WRP_OK) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev_batch, st));
-    h->batch_pending = true;
-    return WRP_OK;
+    if (h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS) return submit_fused(h, in, n_sectors, d_out, (hipStream_t)stream);
+    rc = launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? (hipStream_t)stream : h->stream);
+    if (rc == WRP_OK && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
+        h->fused_armed = true;     // the fused launch gets another chance
+    return rc;
 }
 
 int wrp_check(wrp_handle h)
 {
     if (!h) return WRP_ERR_INVALID;
-    if (h->fused_launches == 0) return WRP_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->batch_pending) HIP_TRY(h, hipEventSynchronize(h->ev_batch));
-    return check_fused(h);
+    const int rc = reap_fused(h, true);
+    if (rc != WRP_OK) return rc;
+    if (h->batch_pending) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_batch));
+        h->batch_pending = false;
+    }
+    return WRP_OK;
 }
+
+int wrp_fused_fallbacks(wrp_handle h) { return h ? h->fused_fallbacks : 0; }
 
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream)
 {
@@ -626,17 +726,12 @@ int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *ou
     int rc = WRP_OK;
     e = hipMemcpyAsync(d_in, iq_host, in_bytes, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) rc = wrp_process_batch_device(h, d_in, n_sectors, d_out, h->stream);
+    if (e == hipSuccess && rc == WRP_OK) rc = wrp_check(h);     // waits; a fused launch that gave up is repeated here
     if (e == hipSuccess && rc == WRP_OK) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (e != hipSuccess) { h->hip_err = hipGetErrorString(e); return WRP_ERR_HIP; }
-    if (rc == WRP_OK && check_fused(h) != WRP_OK) {
-        // the handle now runs the two-kernel path: compute this batch again (hip_err keeps the note)
-        const std::string note = h->hip_err;
-        rc = wrp_process_host(h, iq_host, n_sectors, out_host);
-        h->hip_err = note;
-    }
     return rc;
 }
 
@@ -685,19 +780,24 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
 {
     if (!h || !d_iq || !d_out || n_sectors <= 0 || iters <= 0 || !ms_total) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    int rc = wrp_check(h);                       // idle handle
+    if (rc != WRP_OK) return rc;
+    const int fallbacks = h->fused_fallbacks;
+    // ev0 on the engine's stream; the lanes' streams start behind it; ev1 behind everything the iterations issued
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    for (auto &lane : h->lanes) HIP_TRY(h, hipStreamWaitEvent(lane.stream, h->ev0, 0));
     for (int it = 0; it < iters; it++) {
-        int rc = wrp_process_batch_device(h, d_iq, n_sectors, d_out, h->stream);
+        rc = wrp_process_batch_device(h, d_iq, n_sectors, d_out, nullptr);
         if (rc != WRP_OK) return rc;
     }
+    for (auto &lane : h->lanes) if (lane.used) HIP_TRY(h, hipStreamWaitEvent(h->stream, lane.done, 0));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
-    {
-        const int frc = check_fused(h);
-        if (frc != WRP_OK) return frc;
-    }
-    if ((ms_range || ms_doppler) && h->fused && n_sectors >= WRP_FUSED_MIN_SECTORS) {
+    rc = wrp_check(h);
+    if (rc != WRP_OK) return rc;
+    if (h->fused_fallbacks != fallbacks) return WRP_ERR_HIP;   // a timing that includes a repeated batch is not one (hip_err says why)
+    if ((ms_range || ms_doppler) && h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS) {
         if (ms_range) *ms_range = 0.f;      // one launch: there is no split to report
         if (ms_doppler) *ms_doppler = 0.f;
     } else if (ms_range || ms_doppler) {
@@ -734,6 +834,26 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
     return WRP_OK;
 }
 
+// one fused launch on lane 0 and the engine's stream, waited for; its status word is looked at here (no repeat)
+static int run_fused_sync(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps)
+{
+    int rc = wrp_check(h);
+    if (rc != WRP_OK) return rc;
+    const int slot = h->ring_next;
+    h->ring_next = (h->ring_next + 1) % WRP_RING;
+    rc = launch_fused(h, h->lanes[0], d_iq, n_sectors, d_out, h->stream, slot, d_stamps);
+    if (rc != WRP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const unsigned st = h->h_status[slot];
+    h->h_status[slot] = 0;
+    if (st) {
+        h->lanes[0].ctl_dirty = true;
+        h->hip_err = "fused launch gave up (diagnostic entry: not repeated)";
+        return WRP_ERR_HIP;
+    }
+    return WRP_OK;
+}
+
 int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float *d_out,
                            unsigned long long *host_stamps, size_t host_count)
 {
@@ -745,12 +865,10 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
     unsigned long long *d = nullptr;
     HIP_TRY(h, hipMalloc(&d, count * 8));
     hipError_t e = hipMemsetAsync(d, 0, count * 8, h->stream);
-    int rc = e == hipSuccess ? launch_fused(h, (const float2 *)d_iq, n_sectors, d_out, h->stream, d) : WRP_ERR_HIP;
-    if (e == hipSuccess) e = hipMemcpyAsync(host_stamps, d, count * 8, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    int rc = e == hipSuccess ? run_fused_sync(h, (const float2 *)d_iq, n_sectors, d_out, d) : WRP_ERR_HIP;
+    if (e == hipSuccess) e = hipMemcpy(host_stamps, d, count * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) { h->hip_err = hipGetErrorString(e); return WRP_ERR_HIP; }
-    if (rc == WRP_OK) rc = check_fused(h);
     return rc;
 }
 
@@ -761,11 +879,10 @@ int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_
     const size_t bytes = sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8;
     if (host_bytes < bytes) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc = launch_fused(h, (const float2 *)d_iq, n_sectors, d_out, h->stream);
+    const int rc = run_fused_sync(h, (const float2 *)d_iq, n_sectors, d_out, nullptr);
     if (rc != WRP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(host_mid, h->d_mid_pool, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return check_fused(h);
+    HIP_TRY(h, hipMemcpy(host_mid, h->lanes[0].d_pool, bytes, hipMemcpyDeviceToHost));
+    return WRP_OK;
 }
 
 int wrp_get_config(wrp_handle h, wrp_config *cfg)
@@ -783,5 +900,19 @@ size_t wrp_algorithmic_bytes(wrp_handle h)
     return h ? (size_t)2 * h->cfg.m * h->cfg.n * 8 + (size_t)(h->cfg.m / 2) * 2 * 4 : 0;
 }
 const char *wrp_version(void) { return WRP_VERSION_STRING; }
+
+int wrp_device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return -1;
+    for (char *c = bus; *c; c++) *c = (char)tolower(*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
 
 } // extern "C"

@@ -61,7 +61,16 @@ namespace wrp {
 
 constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_MEMBERS = 32;                  // tile members = row members per team = CUs per XCD
+constexpr int FUSED_MAX_TEAMS = 8;                 // XCDs of the device this is written for
 constexpr int FUSED_STAMP_TASKS = 16;
+#ifndef WRP_FUSED_POLL_SLEEP
+#define WRP_FUSED_POLL_SLEEP 1
+#endif
+#ifndef WRP_FUSED_ROW_POLLERS
+#define WRP_FUSED_ROW_POLLERS 1     // 1: one wave per half polls the L2 and wakes the other three (s_wakeup); 0: every wave polls
+#endif
+constexpr unsigned long long FUSED_JOIN_TICKS = 400000ull;   // 4 ms of s_memrealtime (100 MHz): deadline of the team meeting
+constexpr int FUSED_POLL_SLEEP = WRP_FUSED_POLL_SLEEP;   // s_sleep units (64 cycles) between two polls of a row wave
 constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (task 0)
 constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the gates of ONE half
 constexpr size_t FUSED_TEAM_ELEMS = (size_t)FUSED_SLOT_ROWS * DP_N;   // float2 units: ONE slot[256][512] = 1 MiB per team
@@ -158,15 +167,36 @@ __device__ __forceinline__ unsigned l2_peek_flags(const FusedFlags *line /* wave
 typedef __attribute__((address_space(3))) volatile int lds_word;
 
 // a row wave: wait until every tile member has published `seq`; false = gave up (status set)
+// A poll is one L2 round trip (>= 0.3 us under load) plus the sleep: FUSED_SPIN_BUDGET polls are >= 20 ms, three orders
+// of magnitude above the longest legitimate wait inside the task loop (one task, ~10 us), and the launch reports
+// "workgroups not co-resident" in milliseconds instead of the second the first budget (2^22 polls) took.
+constexpr unsigned FUSED_SPIN_BUDGET = 1u << 16;
 __device__ __forceinline__ bool spin_flags(const FusedFlags *line, unsigned seq, unsigned *status)
 {
 #pragma unroll 1
-    for (unsigned spins = 0; spins < (1u << 22); spins++) {
+    for (unsigned spins = 0; spins < FUSED_SPIN_BUDGET; spins++) {
         if (l2_peek_flags(line, seq) == 0) return true;
         if ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(FUSED_POLL_SLEEP);
     }
     __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// Row waves that do not poll the L2 themselves: the half's polling wave writes the task number it has seen published into
+// an LDS word and pings the workgroup (s_wakeup ends the other waves' s_sleep early), so the sleepers can sleep long --
+// three of four row waves leave the scalar unit, the scalar cache and the L2 alone while they wait (the polls of all
+// eight row waves were 85 % of the launch's 679 k scalar instructions per sector).  A ping that arrives between a
+// wave's look and its s_sleep is lost: that wave then sleeps its 16 x 64 cycles out, once.
+__device__ __forceinline__ bool wait_lds_word(lds_word *word, int want)
+{
+#pragma unroll 1
+    for (unsigned spins = 0; spins < FUSED_SPIN_BUDGET; spins++) {
+        const int v = __builtin_amdgcn_readfirstlane(*word);
+        if (v >= want) return true;
+        if (v < 0) return false;
+        __builtin_amdgcn_s_sleep(16);
+    }
     return false;
 }
 
@@ -179,7 +209,7 @@ __device__ __forceinline__ void spin_flags_sticky(const FusedFlags *line, unsign
     // the whole bounded loop is ONE asm statement: hipcc sees no control flow, so the registers
     // that are live across it (a tile's worth) are not split around a loop and spilled.  The eight
     // dwords of the line land in s[92:99], above what the kernel otherwise uses.
-    unsigned budget = __builtin_amdgcn_readfirstlane(failed ? 1u : (1u << 22));
+    unsigned budget = __builtin_amdgcn_readfirstlane(failed ? 1u : FUSED_SPIN_BUDGET);
     const unsigned have = __builtin_amdgcn_readfirstlane(skip ? 0xffffffffu : 0u);   // 0: look, else: pass
     const unsigned p32 = __builtin_amdgcn_readfirstlane((seq & 0xffu) * 0x01010101u);
     const unsigned long long pat = ((unsigned long long)p32 << 32) | p32;
@@ -377,11 +407,15 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
         // A SIMD issues from its oldest ready wave first, and the tile waves are the critical path of a task; where
         // the younger workgroup had the tile role (it wins the race to the counter on ~3 % of the CUs), that member
         // ran 10 % slower than the others for the whole launch (scalar-probe build, members running free).
+        // Both waits of the meeting have a deadline in REAL time (s_memrealtime, 100 MHz): FUSED_JOIN_TICKS = 4 ms.  The
+        // longest legitimate wait is the tail of the PREVIOUS fused launch of this handle, whose workgroups leave a CU
+        // one after the other while this launch's arrive (the engine overlaps consecutive launches): tens of us.
+        const unsigned long long t_join = __builtin_amdgcn_s_memrealtime();
         unsigned other = 0;
         if (a < 2) {
             __hip_atomic_store(&ctl->cu_block[x][key][a], blockIdx.x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll 1
-            for (unsigned spins = 0; spins < (1u << 16) && !other; spins++) {
+            while (!other && __builtin_amdgcn_s_memrealtime() - t_join < FUSED_JOIN_TICKS) {
                 other = __hip_atomic_load(&ctl->cu_block[x][key][a ^ 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: from the L2
                 if (!other) __builtin_amdgcn_s_sleep(4);
             }
@@ -393,7 +427,7 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
         if (good) {   // the team meets: both kinds complete
             good = 0;
 #pragma unroll 1
-            for (unsigned spins = 0; spins < (1u << 20); spins++) {
+            while (__builtin_amdgcn_s_memrealtime() - t_join < FUSED_JOIN_TICKS) {
                 const unsigned ct = __hip_atomic_load(&ctl->census[0][x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned cr = __hip_atomic_load(&ctl->census[1][x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (ct + cr >= 2u * FUSED_MEMBERS) { good = ct == (unsigned)FUSED_MEMBERS && cr == (unsigned)FUSED_MEMBERS; break; }
@@ -426,6 +460,10 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
 __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status, int xcc, lds_word *s_ctl)
 {
     const int tid = threadIdx.x;
+    // every flag byte this wave has published is in the L2 before the workgroup counts itself as done: the team's last
+    // workgroup zeroes the flag lines, and a byte store still in flight (another L2 channel than the counter) would
+    // land behind the zeroing and deadlock the next launch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned st = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -557,7 +595,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_store(mid, tile_col(q), 0, o);
-            // BEHIND the stores, so that a counted wait can tell them apart
+            // BEHIND the stores, so that a counted wait can tell them apart: the scheduling barrier keeps the four loads
+            // below the eight stores whatever alias analysis says about `iq` (restrict) and the descriptor
+            __builtin_amdgcn_sched_barrier(0);
             fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_group1_to_lds(smem, ga, gc);
             stamp(q, 2);
@@ -594,7 +634,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         doppler_twiddles_to_lds(s_twn, tw_n, tid, FUSED_THREADS);
-        if (tid < 2) s_ctl[12 + tid] = 0;
+        if (tid < 4) s_ctl[12 + tid] = 0;   // 12, 13: arrival counts of the halves; 14, 15: tasks seen published, per half
         __syncthreads();
         const DumpPtrs nodump{};
         const int g = w >> 2;                                  // this wave's half
@@ -604,7 +644,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             stamp(q, 0);
+#if WRP_FUSED_ROW_POLLERS
+            bool there;
+            if ((w & 3) == 0) {   // the half's poller
+                there = spin_flags(my_stored, (unsigned)(q + 1), &ctl->status);
+                if (l == 0) s_ctl[14 + g] = there ? q + 1 : -1;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+            } else {
+                there = wait_lds_word(&s_ctl[14 + g], q + 1);
+            }
+            if (!there) break;                                                    // status is set: the launch is void
+#else
             if (!spin_flags(my_stored, (unsigned)(q + 1), &ctl->status)) break;   // status is set: the launch is void
+#endif
             stamp(q, 1);
             cf x0[8], x1[8];
             const int r0 = rank * 8 + 2 * (w & 3);                 // slot rows of the gates g0, g0 + 1 (either half)

@@ -96,14 +96,20 @@ bool RadarProcessor::read_matrix(int sector, int elevation, int stream)
     // this GPU's pinned slot, pass the turn on
     const long seq = (laps_ * n_elevations + elevation) * (long)n_sectors + sector;
     std::unique_lock<std::mutex> lk(turn_->mu);
-    turn_->cv.wait(lk, [&] { return turn_->ended || turn_->next == seq; });
+    turn_->cv.wait(lk, [&] { return turn_->ended || (turn_->next == seq && !turn_->reading); });
     if (turn_->ended) return false;
     if (max_sectors_ >= 0 && seq >= max_sectors_) {       // the scan's sector budget (a GLOBAL count) is used up
         turn_->ended = true;
         turn_->cv.notify_all();
         return false;
     }
+    // the read itself may block for a whole sector (a UDP recv): not under the mutex, or a thread that has to
+    // announce its failure (rpv2.cpp) could not take it
+    turn_->reading = true;
+    lk.unlock();
     const bool ok = source_((char *)raw, bytes);
+    lk.lock();
+    turn_->reading = false;
     if (ok) turn_->next = seq + 1; else turn_->ended = true;
     turn_->cv.notify_all();
     return ok;

@@ -33,6 +33,7 @@ struct SectorTurnstile {
     std::mutex mu;
     std::condition_variable cv;
     long next = 0;        // global sequence number (elevation * n_sectors + sector) of the sector to be read next
+    bool reading = false; // a processor is inside the (blocking) source call -- made WITHOUT the mutex held
     bool ended = false;   // the source is exhausted (or failed): nobody reads any more
     std::mutex sink_mu;   // frames of different GPUs leave through one sink, one frame at a time
 };

@@ -1,10 +1,12 @@
 // rpv2.cpp -- entry point with the reference's name (Makefile:4 builds `rpv2`; main.cpp:3-16 is
 // the class-based variant).  usage:
-//   rpv2 [num_streams] [--in udp:PORT | file:PATH | synthetic] [--out udp:PORT_ZDB,PORT_ZDR[@IPV4] | file:PATH | none]
+//   rpv2 [num_streams] [--in udp:PORT | file:PATH | synthetic | synthetic:copy[:T]] [--bind-numa] [--out udp:PORT_ZDB,PORT_ZDR[@IPV4] | file:PATH | none]
 //        [--sectors N] [--device D | --devices D0,D1,...] [--no-elevation] [--scan SECTORS,ELEVATIONS]
 // Defaults reproduce main.cpp:10-15: 143 sectors x 9 elevations of 1024 x 512, UDP 19001 in,
 // 19002 / 19003 out (broadcast, as the reference; @IPV4 sends the products to one host instead).  file: input is a concatenation of wire-format sectors (12 bytes/sample),
-// file: output a concatenation of frames, Zdb then Zdr per sector.
+// file: output a concatenation of frames, Zdb then Zdr per sector.  Frame header: [sector BE16] for udp: products
+// (read_single.cc:510-517), [sector BE16][elevation BE16] (rpv2.cu:631-661) for file: -- keyed on the OUTPUT endpoint;
+// --no-elevation forces the short header.
 //
 // --devices: ONE host thread and ONE engine handle per listed GPU (a device may be listed twice to
 // rehearse on a smaller box); sector s of every elevation goes to GPU number s mod G of the list; the
@@ -14,6 +16,12 @@
 // GPUs interleave on the output (each frame names its sector and elevation).
 // --in synthetic: the pinned slots keep whatever they hold (zeros at start): transport + GPU pipeline
 // rate without a real source.  The run's wall-clock rate is printed on stderr.
+// --in synthetic:copy[:T]: every sector is COPIED into its pinned slot from an ordinary pageable buffer of the
+// feeder thread (6 MiB per sector, as a socket delivers it), by the feeder thread and T - 1 helpers (default
+// T = 1): the end-to-end rate WITH the host's share of the work.  Each GPU thread has a source of its own
+// (no turnstile), and --sectors counts per GPU.
+// --bind-numa: every GPU thread (and its helpers) runs on the CPUs of the NUMA node its GPU hangs on.
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,13 +32,100 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
 #include "radar_processor.h"
+
+namespace {
+
+// memcpy of one sector split over T threads (the caller is one of them); the helpers live as long as the pool
+class FillPool {
+  public:
+    explicit FillPool(int threads) : n_(threads < 1 ? 1 : threads)
+    {
+        for (int t = 1; t < n_; t++) workers_.emplace_back([this, t] { run(t); });
+    }
+    ~FillPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    void copy(char *dst, const char *src, size_t bytes)
+    {
+        if (n_ == 1) { memcpy(dst, src, bytes); return; }
+        { std::lock_guard<std::mutex> lk(mu_); dst_ = dst; src_ = src; bytes_ = bytes; left_ = n_ - 1; gen_++; }
+        cv_.notify_all();
+        part(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return left_ == 0; });
+    }
+
+  private:
+    void part(int t)
+    {
+        const size_t chunk = ((bytes_ + n_ - 1) / n_ + 4095) & ~(size_t)4095, lo = (size_t)t * chunk;
+        if (lo < bytes_) memcpy(dst_ + lo, src_ + lo, lo + chunk <= bytes_ ? chunk : bytes_ - lo);
+    }
+    void run(int t)
+    {
+        long seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+            part(t);
+            { std::lock_guard<std::mutex> lk(mu_); left_--; }
+            done_.notify_one();
+        }
+    }
+    const int n_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    long gen_ = 0;
+    int left_ = 0;
+    bool stop_ = false;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+// the calling thread (and every thread it starts later) onto the CPUs of the GPU's NUMA node; false = left alone
+bool bind_to_gpu_numa(int device)
+{
+    const int node = wrp_device_numa_node(device);
+    if (node < 0) return false;
+    char path[96], list[4096] = {0};
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t want, have, set;
+    CPU_ZERO(&want);
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1) b = a;
+        if (k >= 1) for (int c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &want);
+    }
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return false;
+    CPU_AND(&set, &want, &have);
+    if (CPU_COUNT(&set) == 0) return false;       // the node's CPUs are outside what this process may use
+    return sched_setaffinity(0, sizeof set, &set) == 0;
+}
+
+} // namespace
 
 int main(int argc, char **argv)
 {
     int num_streams = 2;
     long sectors = -1;
-    bool with_elev = true, with_elev_set = false;
+    bool with_elev = true, with_elev_set = false, bind_numa = false;
     int scan_sectors = 143, scan_elevations = 9;
     std::vector<int> devices{0};
     std::string in = "udp:19001", out = "udp:19002,19003";
@@ -50,6 +145,7 @@ int main(int argc, char **argv)
                 return 2;
             }
         } else if (a == "--no-elevation") { with_elev = false; with_elev_set = true; }
+        else if (a == "--bind-numa") bind_numa = true;
         else if (a[0] != '-') { num_streams = atoi(a.c_str()); if (num_streams < 1) num_streams = 1; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -60,8 +156,12 @@ int main(int argc, char **argv)
         procs.emplace_back(new RadarProcessor(scan_sectors, 1024, 512, scan_elevations, num_streams));
         procs[g]->set_device(devices[g]);
         procs[g]->set_max_sectors(sectors);
-        if (G > 1) procs[g]->set_shard(g, G, &turn);
+        if (G > 1) procs[g]->set_shard(g, G, in.rfind("synthetic", 0) == 0 ? nullptr : &turn);   // synthetic: a source per GPU
     }
+    const bool copy_source = in.rfind("synthetic:copy", 0) == 0;
+    const int fill_threads = copy_source && in.size() > 15 ? atoi(in.c_str() + 15) : 1;
+    std::vector<std::unique_ptr<FillPool>> pools(G);
+    std::vector<std::vector<char>> pageable(G);
     FILE *fin = nullptr, *fout = nullptr;
     std::unique_ptr<udpbroadcast::udpserver> server;
     std::vector<std::unique_ptr<udpbroadcast::udpclient>> clients;
@@ -78,24 +178,32 @@ int main(int argc, char **argv)
                 fin = fopen(in.c_str() + 5, "rb");
                 if (!fin) { perror("input"); return 2; }
                 src = [fin](char *buf, size_t bytes) { return fread(buf, 1, bytes, fin) == bytes; };
-            } else if (in == "synthetic") {
-                src = [](char *, size_t) { return true; };
+            } else if (in == "synthetic" || copy_source) {
+                src = [](char *, size_t) { return true; };     // synthetic:copy: per GPU thread, set where the thread starts
             } else if (in.rfind("udp:", 0) == 0) {
                 server.reset(new udpbroadcast::udpserver(atoi(in.c_str() + 4)));
                 udpbroadcast::udpserver *sv = server.get();
-                src = [sv](char *buf, size_t bytes) {   // one datagram per range row (read_single.cc:145-148)
+                // several GPU threads share the socket: a reader waiting on a source that has gone quiet looks at the
+                // turnstile every 200 ms, so that the failure of another GPU's thread ends the run instead of hanging it
+                if (G > 1) sv->set_timeout_ms(200);
+                SectorTurnstile *tn = G > 1 ? &turn : nullptr;
+                src = [sv, tn](char *buf, size_t bytes) {   // one datagram per range row (read_single.cc:145-148)
                     const size_t row = (size_t)NUM_BYTES_PER_SAMPLE * 512;
-                    for (size_t off = 0; off < bytes; off += row)
-                        if (sv->recv(buf + off, row) != (int)row) return false;
+                    for (size_t off = 0; off < bytes;) {
+                        const int got = sv->recv(buf + off, row);
+                        if (got == (int)row) { off += row; continue; }
+                        if (got < 0 && (errno == EAGAIN || errno == EWOULDBLOCK) && tn && !tn->ended) continue;
+                        return false;
+                    }
                     return true;
                 };
-                if (!with_elev_set) with_elev = false, with_elev_set = true;   // UDP products: 2-byte header
             } else { fprintf(stderr, "unknown --in %s\n", in.c_str()); return 2; }
             if (out.rfind("file:", 0) == 0) {
                 fout = fopen(out.c_str() + 5, "wb");
                 if (!fout) { perror("output"); return 2; }
                 sink = [fout](int, int, int, const unsigned char *f, size_t n) { fwrite(f, 1, n, fout); };
             } else if (out.rfind("udp:", 0) == 0) {
+                if (!with_elev_set) with_elev = false, with_elev_set = true;   // UDP products carry the 2-byte header (read_single.cc:510-517)
                 int ports[2] = {19002, 19003};
                 sscanf(out.c_str() + 4, "%d,%d", &ports[0], &ports[1]);
                 const size_t at = out.find('@');
@@ -118,13 +226,27 @@ int main(int argc, char **argv)
     procs[0]->set_on_ready([] { fprintf(stderr, "rpv2: ready\n"); fflush(stderr); });
 
     std::vector<int> rcs(G, 0);
+    std::vector<int> bound(G, 0);
+    // runs on the GPU's own thread: NUMA binding first, so that the helpers and the pageable buffer (first touch) follow it
+    auto prepare = [&](int g) {
+        if (bind_numa) bound[g] = bind_to_gpu_numa(devices[g]);
+        if (!copy_source) return;
+        const size_t bytes = (size_t)NUM_BYTES_PER_SAMPLE * 1024 * 512;
+        pageable[g].assign(bytes, (char)(g + 1));
+        pools[g].reset(new FillPool(fill_threads));
+        FillPool *pool = pools[g].get();
+        const char *from = pageable[g].data();
+        procs[g]->set_source([pool, from, bytes](char *buf, size_t n) { pool->copy(buf, from, n < bytes ? n : bytes); return true; });
+    };
     const auto t0 = std::chrono::steady_clock::now();
     if (G == 1) {
+        prepare(0);
         rcs[0] = procs[0]->start();
     } else {
         std::vector<std::thread> threads;
         for (int g = 0; g < G; g++)
             threads.emplace_back([&, g] {
+                prepare(g);
                 try { rcs[g] = procs[g]->start(); } catch (const char *msg) { fprintf(stderr, "socket: %s\n", msg); rcs[g] = 3; }
                 if (rcs[g]) {   // a GPU that failed must not leave the others waiting for its turn
                     std::lock_guard<std::mutex> lk(turn.mu);
@@ -146,7 +268,10 @@ int main(int argc, char **argv)
         if (rcs[g]) { fprintf(stderr, "rpv2: GPU %d: %s\n", devices[g], procs[g]->last_error()); rc = 1; }
         else if (G > 1) fprintf(stderr, "rpv2: GPU %d (shard %d of %d): %ld sectors\n", devices[g], g, G, procs[g]->sectors_done());
     }
-    if (!rc) fprintf(stderr, "rpv2: %ld sectors processed in %.3f s (%.0f sectors/s end to end, %d GPU thread%s, %d slots each)\n", total,
-                     dt, total / dt, G, G > 1 ? "s" : "", num_streams);
+    pools.clear();
+    if (!rc) fprintf(stderr, "rpv2: %ld sectors processed in %.3f s (%.0f sectors/s end to end, %d GPU thread%s, %d slots each%s%s)\n", total,
+                     dt, total / dt, G, G > 1 ? "s" : "", num_streams,
+                     copy_source ? (std::string(", host fill by ") + std::to_string(fill_threads) + " thread(s) per GPU").c_str() : "",
+                     bind_numa ? (bound[0] ? ", NUMA-bound" : ", NUMA binding not possible") : "");
     return rc;
 }

@@ -4,6 +4,7 @@
 #include <arpa/inet.h>
 #include <string.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 namespace udpbroadcast {
@@ -61,6 +62,14 @@ udpserver::udpserver(int port)
 }
 
 udpserver::~udpserver() {}
+
+void udpserver::set_timeout_ms(int ms)
+{
+    timeval tv;
+    tv.tv_sec = ms / 1000;
+    tv.tv_usec = (ms % 1000) * 1000;
+    ::setsockopt(sock_.fd(), SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+}
 
 int udpserver::recv(char *buffer, size_t length)
 {

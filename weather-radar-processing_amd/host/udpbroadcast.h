@@ -47,6 +47,9 @@ class udpserver {
     udpserver(int port);                            // throws "error bind"
     ~udpserver();
     int recv(char *buffer, size_t length);          // bytes received or -1
+    // extension (not in the reference): recv gives up after `ms` milliseconds without a datagram (-1, errno EAGAIN),
+    // so that a reader can look at a stop flag; 0 = block for ever (the default)
+    void set_timeout_ms(int ms);
   private:
     detail::DatagramSocket sock_;
     sockaddr_in from_;
