@@ -144,17 +144,16 @@ int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr);
  * stream: hipStream_t as void*, NULL = the engine's compute stream.  Asynchronous. */
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream);
 int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream);
-/* Completion and ordering.  With a caller's stream the batch is ordered on that stream like any kernel.
- * With stream = NULL the engine uses streams of its own and CONSECUTIVE BATCHES MAY OVERLAP (the
- * workgroups of batch k + 1 move onto the CUs as the teams of batch k leave them): do not feed one
- * batch's output into the next without a wrp_check in between.
- * wrp_check waits for every batch submitted so far.  The fused launch needs all its workgroups resident
- * at once and says so, within milliseconds, when they are not (e.g. another kernel occupies CUs); such a
- * batch is REPEATED on the two-kernel path -- by wrp_check, or by the next wrp_process_batch_device once
- * the launch has completed -- so d_out is valid once wrp_check has returned WRP_OK, and must not be
- * consumed before that.  The handle then stays on the two kernels for 16 batches and tries the fused
- * launch again; wrp_last_hip_error holds a note, wrp_fused_fallbacks the count of repeated batches.
- * wrp_process_host and wrp_time_batch_device check by themselves. */
+/* Completion and ordering.  The batch is ordered on the stream it is given (NULL: the engine's own stream);
+ * ONE fused launch is in flight per handle: a batch on another stream first waits, on the device, for the
+ * previous one.  wrp_check waits for every batch submitted so far.
+ * The fused launch needs all its workgroups resident at once and says so, within milliseconds, when they
+ * are not (e.g. another kernel occupies CUs); such a batch is REPEATED on the two-kernel path -- by
+ * wrp_check, or by the next wrp_process_batch_device once the launch has completed -- so d_out is valid
+ * once wrp_check has returned WRP_OK, and must not be consumed before that.  The handle then stays on the
+ * two kernels for 16 batches and tries the fused launch again; wrp_last_hip_error holds a note,
+ * wrp_fused_fallbacks the count of repeated batches.  wrp_process_host and wrp_time_batch_device check by
+ * themselves. */
 int wrp_check(wrp_handle h);
 int wrp_fused_fallbacks(wrp_handle h);
 

@@ -264,10 +264,10 @@ def test_fused_launch_that_cannot_form_its_teams_is_repeated(wrp, sectors):
         assert b"two-kernel path" in e.lib.wrp_last_hip_error(e.handle)
 
 
-def test_consecutive_fused_batches_overlap_and_stay_bit_identical(wrp, sectors):
-    """With stream = NULL the engine alternates between two lanes (control block + hand-over slots + stream each), so
-    the workgroups of batch k + 1 move onto the CUs while the last teams of batch k finish.  Many batches back to back,
-    different inputs and outputs, every one bit-identical to the two-kernel path; wrp_check waits for all of them."""
+def test_consecutive_fused_batches_stay_bit_identical(wrp, sectors):
+    """Many fused batches back to back without a host synchronisation in between, different inputs and outputs (every
+    launch leaves the control block zeroed for the next one), every one bit-identical to the two-kernel path; wrp_check
+    waits for all of them."""
     import torch
     count = 24
     batches = [np.stack([sectors[(k + j) % 3] * np.float32(1 + 0.5 * ((k + j) % 4)) for k in range(count)]) for j in range(3)]

@@ -120,7 +120,8 @@ def load_library():
     lib.wrp_process_batch_device.argtypes = [vp, vp, i, vp, vp]
     lib.wrp_process_host.argtypes = [vp, vp, i, vp]
     lib.wrp_check.argtypes = [vp]
-    lib.wrp_fused_fallbacks.argtypes = [vp]
+    if hasattr(lib, "wrp_fused_fallbacks"):      # absent from older builds that tools/ab.py may load beside this one
+        lib.wrp_fused_fallbacks.argtypes = [vp]
     lib.wrp_debug_fused_mid.argtypes = [vp, vp, i, vp, vp, C.c_size_t]
     lib.wrp_dump_stage.argtypes = [vp, i, i, i, vp]
     lib.wrp_time_batch_device.argtypes = [vp, vp, i, vp, i, fp, fp, fp]

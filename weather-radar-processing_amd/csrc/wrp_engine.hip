@@ -42,14 +42,13 @@ constexpr int WRP_RING = 64;            // fused batches that may be outstanding
 constexpr int WRP_FUSED_COOLDOWN = 16;  // batches on the two-kernel path after a fused launch that gave up
 
 struct FusedLane {
-    hipStream_t stream = nullptr;       // used when the caller passes no stream
     wrp::FusedCtl *d_ctl = nullptr;
     float2 *d_pool = nullptr;           // per XCD team: ONE hand-over slot of 1 MiB
     hipEvent_t done = nullptr;          // the lane's last launch: the next one on this lane waits for it (workspace)
     bool used = false;
     bool ctl_dirty = true;              // memset before the next launch (first launch, after a failure)
 };
-struct FusedBatch { const float2 *in; int n; float *out; int slot; int lane; };
+struct FusedBatch { const float2 *in; int n; float *out; int slot; };
 
 } // namespace
 
@@ -69,17 +68,17 @@ struct wrp_engine {
     bool tuned_b = false;     // m = 2048, n = 128 (BASELINE configs[4]): wrp_shape_b.h; its stage dumps come from wrp_generic.h
     bool persist = false;     // range pass as a fixed grid walking the tiles with prefetch
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
-    // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors.  Two LANES, each with its own
-    // control block, hand-over slots and stream: consecutive batches alternate between them, so the workgroups of batch
-    // k + 1 move onto the CUs as the teams of batch k leave them (a launch costs ~60 us beyond its sectors: team
-    // meeting, first tile, the rows of the last task, teams that finish early -- all of it now under the other lane).
+    // fused persistent launch (wrp_fused.h): batches of >= WRP_FUSED_MIN_SECTORS sectors, ONE in flight per handle (control
+    // block and hand-over slots are the handle's; a launch needs every CU, so two could only collide).  Measured: a second
+    // workspace and stream, with the next launch held at a gate kernel until the running one is resident, bought 1 % (the
+    // dispatcher deals workgroups to the XCDs in order, so the next launch moves in only when the slowest team has left)
+    // and depended on how streams map to hardware queues -- not kept.
     bool fused = false;             // the shape and the flags allow the fused launch
     bool fused_armed = false;       // ... and it is in use (false for WRP_FUSED_COOLDOWN batches after one that gave up)
     int fused_cooldown = 0;
     int fused_fallbacks = 0;        // batches that were repeated on the two-kernel path
     int n_cus = 0;
-    FusedLane lanes[2];
-    int next_lane = 0;
+    FusedLane lane;
     hipEvent_t ev_ring[WRP_RING] = {};   // completion of fused batch `slot`
     unsigned *h_status = nullptr;   // pinned + mapped: word `slot` is written by the fused launch itself, only when it failed
     unsigned *d_status = nullptr;   // the same words as the device sees them
@@ -312,7 +311,7 @@ int redo_batch(wrp_engine *h, const FusedBatch &b, unsigned status)
     h->fused_armed = false;
     h->fused_cooldown = WRP_FUSED_COOLDOWN;
     h->fused_fallbacks++;
-    h->lanes[b.lane].ctl_dirty = true;
+    h->lane.ctl_dirty = true;
     const std::string note = (status & 2)
         ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; batch repeated on the two-kernel path"
         : "fused launch: a bounded wait gave up (workgroups not co-resident?); batch repeated on the two-kernel path";
@@ -348,7 +347,7 @@ int reap_fused(wrp_engine *h, bool block, size_t leave = 0)
     return WRP_OK;
 }
 
-// fused launch of one batch on the next lane; st = the caller's stream or nullptr (the lane's own)
+// fused launch of one batch; stream = the caller's or nullptr (the engine's)
 int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream)
 {
     if (h->outstanding.size() >= (size_t)WRP_RING) {
@@ -356,11 +355,9 @@ int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, h
         if (rc != WRP_OK) return rc;
         if (!h->fused_armed) return launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? stream : h->stream);
     }
-    const int li = h->next_lane;
-    h->next_lane ^= 1;
-    FusedLane &lane = h->lanes[li];
-    hipStream_t st = stream ? stream : lane.stream;
-    if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // the lane's control block and slots are free again
+    FusedLane &lane = h->lane;
+    hipStream_t st = stream ? stream : h->stream;
+    if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // control block and slots are free again (free on one stream)
     const int slot = h->ring_next;
     h->ring_next = (h->ring_next + 1) % WRP_RING;
     const int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot);
@@ -368,7 +365,7 @@ int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, h
     HIP_TRY(h, hipEventRecord(h->ev_ring[slot], st));
     HIP_TRY(h, hipEventRecord(lane.done, st));
     lane.used = true;
-    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, li});
+    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot});
     return WRP_OK;
 }
 
@@ -406,12 +403,9 @@ int destroy_impl(wrp_engine *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->d_mid) (void)hipFree(h->d_mid);
-    for (auto &lane : h->lanes) {
-        if (lane.stream) { (void)hipStreamSynchronize(lane.stream); (void)hipStreamDestroy(lane.stream); }
-        if (lane.done) (void)hipEventDestroy(lane.done);
-        if (lane.d_ctl) (void)hipFree(lane.d_ctl);
-        if (lane.d_pool) (void)hipFree(lane.d_pool);
-    }
+    if (h->lane.done) (void)hipEventDestroy(h->lane.done);
+    if (h->lane.d_ctl) (void)hipFree(h->lane.d_ctl);
+    if (h->lane.d_pool) (void)hipFree(h->lane.d_pool);
     for (auto &e : h->ev_ring) if (e) (void)hipEventDestroy(e);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->d_dump) (void)hipFree(h->d_dump);
@@ -459,12 +453,9 @@ int create_impl(wrp_engine *h)
     WRP_FUSED_ATTR(7, false); WRP_FUSED_ATTR(9, false);
     WRP_FUSED_ATTR(7, true);  WRP_FUSED_ATTR(9, true);
 #undef WRP_FUSED_ATTR
-    for (auto &lane : h->lanes) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
-        HIP_TRY(h, hipMalloc(&lane.d_ctl, sizeof(wrp::FusedCtl)));
-        HIP_TRY(h, hipMalloc(&lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
-    }
+    HIP_TRY(h, hipEventCreateWithFlags(&h->lane.done, hipEventDisableTiming));
+    HIP_TRY(h, hipMalloc(&h->lane.d_ctl, sizeof(wrp::FusedCtl)));
+    HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
     for (auto &e : h->ev_ring) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * WRP_RING, hipHostMallocMapped));
     std::memset(h->h_status, 0, sizeof(unsigned) * WRP_RING);
@@ -783,14 +774,11 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
     int rc = wrp_check(h);                       // idle handle
     if (rc != WRP_OK) return rc;
     const int fallbacks = h->fused_fallbacks;
-    // ev0 on the engine's stream; the lanes' streams start behind it; ev1 behind everything the iterations issued
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    for (auto &lane : h->lanes) HIP_TRY(h, hipStreamWaitEvent(lane.stream, h->ev0, 0));
     for (int it = 0; it < iters; it++) {
         rc = wrp_process_batch_device(h, d_iq, n_sectors, d_out, nullptr);
         if (rc != WRP_OK) return rc;
     }
-    for (auto &lane : h->lanes) if (lane.used) HIP_TRY(h, hipStreamWaitEvent(h->stream, lane.done, 0));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
@@ -834,20 +822,20 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
     return WRP_OK;
 }
 
-// one fused launch on lane 0 and the engine's stream, waited for; its status word is looked at here (no repeat)
+// one fused launch on the engine's stream, waited for; its status word is looked at here (no repeat)
 static int run_fused_sync(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps)
 {
     int rc = wrp_check(h);
     if (rc != WRP_OK) return rc;
     const int slot = h->ring_next;
     h->ring_next = (h->ring_next + 1) % WRP_RING;
-    rc = launch_fused(h, h->lanes[0], d_iq, n_sectors, d_out, h->stream, slot, d_stamps);
+    rc = launch_fused(h, h->lane, d_iq, n_sectors, d_out, h->stream, slot, d_stamps);
     if (rc != WRP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const unsigned st = h->h_status[slot];
     h->h_status[slot] = 0;
     if (st) {
-        h->lanes[0].ctl_dirty = true;
+        h->lane.ctl_dirty = true;
         h->hip_err = "fused launch gave up (diagnostic entry: not repeated)";
         return WRP_ERR_HIP;
     }
@@ -881,7 +869,7 @@ int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_
     HIP_TRY(h, hipSetDevice(h->device));
     const int rc = run_fused_sync(h, (const float2 *)d_iq, n_sectors, d_out, nullptr);
     if (rc != WRP_OK) return rc;
-    HIP_TRY(h, hipMemcpy(host_mid, h->lanes[0].d_pool, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(host_mid, h->lane.d_pool, bytes, hipMemcpyDeviceToHost));
     return WRP_OK;
 }
 

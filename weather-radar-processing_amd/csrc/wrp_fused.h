@@ -63,11 +63,21 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_MEMBERS = 32;                  // tile members = row members per team = CUs per XCD
 constexpr int FUSED_MAX_TEAMS = 8;                 // XCDs of the device this is written for
 constexpr int FUSED_STAMP_TASKS = 16;
+// Row waves and the hand-over flags (profiles/r03/ab_polling.log, us/sector, one process, builds interleaved):
+//   every row wave polls the L2 itself, s_sleep 1 between polls (round 2's form)          2.469
+//   the same, s_sleep 4                                                                     2.459   <- kept
+//   ONE wave per half polls and wakes the other three through an LDS word + s_wakeup        2.631 (sleep 1), 2.593 (sleep 4)
+// The scalar instructions of the polls are 85 % of the launch's scalar instructions, but what a row wave buys with them is
+// the time at which it NOTICES a half: the tile members wait at their look for the slowest row wave of the team, and every
+// tenth of a microsecond added to a notice is added to the task (a poller costs 6 %).
 #ifndef WRP_FUSED_POLL_SLEEP
-#define WRP_FUSED_POLL_SLEEP 1
+#define WRP_FUSED_POLL_SLEEP 4
+#endif
+#ifndef WRP_FUSED_WAIT_SLEEP
+#define WRP_FUSED_WAIT_SLEEP 16      // (poller form only) s_sleep units of a row wave that waits for its half's poller
 #endif
 #ifndef WRP_FUSED_ROW_POLLERS
-#define WRP_FUSED_ROW_POLLERS 1     // 1: one wave per half polls the L2 and wakes the other three (s_wakeup); 0: every wave polls
+#define WRP_FUSED_ROW_POLLERS 0     // 1: one wave per half polls the L2 and wakes the other three (measured slower: above)
 #endif
 constexpr unsigned long long FUSED_JOIN_TICKS = 400000ull;   // 4 ms of s_memrealtime (100 MHz): deadline of the team meeting
 constexpr int FUSED_POLL_SLEEP = WRP_FUSED_POLL_SLEEP;   // s_sleep units (64 cycles) between two polls of a row wave
@@ -195,7 +205,7 @@ __device__ __forceinline__ bool wait_lds_word(lds_word *word, int want)
         const int v = __builtin_amdgcn_readfirstlane(*word);
         if (v >= want) return true;
         if (v < 0) return false;
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(WRP_FUSED_WAIT_SLEEP);
     }
     return false;
 }
@@ -266,41 +276,49 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
 // k1 < 8 goes to the LDS image (group 0), k1 >= 8 stays in ga / gc (group 1).  The lane's two columns
 // are transformed ONE AFTER THE OTHER (and written as 8-byte halves of their 16-byte slots): both at
 // once need more registers than the 128 that four waves per SIMD leave (165 in range_pass_1024).
-__device__ __forceinline__ void fused_stage1_column(unsigned char *smem, cf (&a)[16], int p0, int slot, cf (&g)[8])
-{
-    typedef FusedTile T;
-    fft16<-1>(a);
-    const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);   // k1 further on: a compile-time offset
-    *reinterpret_cast<float2 *>(smem + slot) = a[0];
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
-        *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t);
-    }
-#pragma unroll
-    for (int k1 = 8; k1 < 16; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
-        g[k1 - 8] = cmul(a[k1], t);
-    }
-}
-template <int COLUMN>   // 0: the lane's first column (v[r].xy), 1: its second (v[r].zw)
-__device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&g)[8])
+// The lane's fifteen twiddles are the same for both columns: they are read from LDS ONCE per task, in ONE batch in front
+// of the first butterfly (fused_stage1_tables), and a column's sixteen window values in one batch too -- read at their
+// points of use, as the first form did, every one of the 46 reads is followed by its own s_waitcnt lgkmcnt(0) a few
+// instructions later, and a tile wave (two per SIMD) then stands through 46 LDS round trips per task in this stage alone.
+struct FusedStage1Tables { cf tw[16]; };
+__device__ __forceinline__ void fused_stage1_tables(const unsigned char *smem, FusedStage1Tables &t)
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // per-lane LDS addresses are recomputed per tile, not hoisted + spilled
     tid &= FUSED_THREADS - 1;       // (the compiler knows the range again: address arithmetic folds)
+    const int w = tid >> 6, l = tid & 63;
+    const int p0 = w * 8 + (l >> 3);
+    const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);   // k1 further on: a compile-time offset
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++) t.tw[k1] = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
+}
+template <int COLUMN>   // 0: the lane's first column (v[r].xy), 1: its second (v[r].zw)
+__device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const FusedStage1Tables &t, cf (&g)[8])
+{
+    typedef FusedTile T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
-    const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
     const int slot = T::addr(p0, cp) + 8 * COLUMN;   // position k1*64 + p0 is 8 k1 blocks further on
+    const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
+    float wr[16];    // one batch of eight reads (the window of the column's sixteen rows), one wait
+#pragma unroll
+    for (int r = 0; r < 16; r++) wr[r] = s_wr[p0 + 64 * r];
     cf a[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float wgt = s_wr[p0 + 64 * r] * (COLUMN ? wdv.y : wdv.x);
+        const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
         a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
     }
-    fused_stage1_column(smem, a, p0, slot, g);
+    fft16<-1>(a);
+    *reinterpret_cast<float2 *>(smem + slot) = a[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t.tw[k1]);
+#pragma unroll
+    for (int k1 = 8; k1 < 16; k1++) g[k1 - 8] = cmul(a[k1], t.tw[k1]);
 }
 
 // group 1 from its registers into the image (after group 0 has left it)
@@ -337,16 +355,15 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
 #pragma unroll
     for (int it = 0; it < 2; it++) {   // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
         const int p1 = (l >> 4) + 4 * it;
-        cf a[8];
+        cf a[8], t[8];   // the seven twiddles in one batch with the data, not one LDS round trip each
 #pragma unroll
         for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
+#pragma unroll
+        for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
         fft8<-1>(a);
         *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) {
-            const cf t = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
-            *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t);
-        }
+        for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t[k2]);
     }
     wave_lds_fence();
 }
@@ -407,9 +424,8 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
         // A SIMD issues from its oldest ready wave first, and the tile waves are the critical path of a task; where
         // the younger workgroup had the tile role (it wins the race to the counter on ~3 % of the CUs), that member
         // ran 10 % slower than the others for the whole launch (scalar-probe build, members running free).
-        // Both waits of the meeting have a deadline in REAL time (s_memrealtime, 100 MHz): FUSED_JOIN_TICKS = 4 ms.  The
-        // longest legitimate wait is the tail of the PREVIOUS fused launch of this handle, whose workgroups leave a CU
-        // one after the other while this launch's arrive (the engine overlaps consecutive launches): tens of us.
+        // Both waits of the meeting have a deadline in REAL time (s_memrealtime, 100 MHz): FUSED_JOIN_TICKS = 4 ms; the
+        // workgroups of a launch that has the GPU to itself arrive within microseconds of each other.
         const unsigned long long t_join = __builtin_amdgcn_s_memrealtime();
         unsigned other = 0;
         if (a < 2) {
@@ -488,7 +504,7 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
 }
 
 template <int TAPS, bool STAMPS>
-__global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
+__global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]
     float *__restrict__ out,         // [S][512][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
@@ -566,7 +582,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
         for (int q = 0; q < tasks; q++) {
             cf ga[8], gc[8];
             stamp(q, 0);
-            fused_stage1<0>(smem, v, wdv, ga);
+            FusedStage1Tables s1t;
+            fused_stage1_tables(smem, s1t);
+            fused_stage1<0>(smem, v, wdv, s1t, ga);
             // Half 1 of the previous tile was stored half a stage ago: its drain costs nothing here.  It is
             // counted NOW, while this CU has no request in flight (the row members load that half at once,
             // and L2 hits of a CU queue -- 3.5 us measured -- behind a request burst that went out before
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void fused_chain_1024x512(
             int last = 0;
             if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
             if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
-            fused_stage1<1>(smem, v, wdv, gc);
+            fused_stage1<1>(smem, v, wdv, s1t, gc);
             __syncthreads();                    // A1: group 0 is in the image
             stamp(q, 1);
             // v is free: the next tile is requested a quarter at a time over the rest of this one

@@ -1,0 +1,329 @@
+// wrp_fused_b.h -- BASELINE configs[4] (m = 2048 range cells x n = 128 pulses) in ONE persistent launch: the team
+// protocol of wrp_fused.h (XCD teams of 32 tile + 32 row workgroups, one 1 MiB hand-over slot per XCD that never
+// leaves its L2, byte flags, bounded waits, self-zeroing control block) around the arithmetic of wrp_shape_b.h.
+// The reference cannot run this shape at all (rpv2.cu:84,145-148); the two-kernel form (range_pass_2048 +
+// doppler_pass_128) moves the 4 MiB intermediate of a sector out to HBM and back: 2.0 x the algorithmic bytes.
+//
+// What differs from the 1024 x 512 launch:
+//   * a sector is ONE task: its two channels are transformed side by side -- tile member t takes channel t >> 4 and
+//     the 8-COLUMN tile t & 15 (2048 rows x 64 bytes = the same 128 KiB of registers per workgroup as 1024 rows x
+//     128 bytes; the two members t, t ^ 1 ask for the two halves of every 128-byte line at the same time);
+//   * 2048 = 16 x 16 x 8: stage 1 (registers) radix 16 over rows p0 + 128 r, stage 2 (LDS, wave-local) radix 16 over
+//     positions p1 + 8 r of the sub-transform the wave owns, stage 3 radix 8; the sixteen 128-point sub-transforms go
+//     through LDS in two groups of eight as there, the gates of group g are those with (gate mod 16) in [8 g, 8 g + 8):
+//     half g of the slot, [2 channels][512 rows][128] complex, row (gate >> 4) * 8 + (gate & 7);
+//   * LDS: the group image [8 k1][16 blocks of 8 positions x 64 B + 64 B of padding] is 72 KiB as there; its 128 pads
+//     hold the stage-1 twiddles W_2048^{p0 k1} for k1 = 1 .. 8 only (one pad per p0) -- k1 = 9 .. 15 are the products
+//     W^{8 p0} W^{(k1 - 8) p0} (seven complex multiplies per lane and tile; range_pass_2048 forms them the same way,
+//     so the two forms stay bit-identical) -- and the range window is kept as its first half (it is symmetric: the
+//     engine stores wr_c[i] = wr_c[m - 1 - i] exactly): 78,912 bytes, two workgroups per CU;
+//   * a row wave transforms FOUR rows at a time (16 lanes per row, 128 = 8 x 4 x 4: doppler_row_128), the HH and the
+//     VV row of two gates, so Zdb and Zdr leave with the task that produced them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wrp_fused.h"
+#include "wrp_shape_b.h"
+
+namespace wrp {
+
+struct FusedTileB {
+    static constexpr int ROW_BYTES = 64, BLK_BYTES = 9 * ROW_BYTES, BLOCKS = 128;
+    static constexpr int IMG_BYTES = BLOCKS * BLK_BYTES;          // 73728
+    static constexpr int OFF_WR = IMG_BYTES;                      // float wr_c[1024]: the first half of the window
+    static constexpr int OFF_CTL = OFF_WR + (RB_M / 2) * 4;       // 77824: control words, both kinds (as FusedTile)
+    static constexpr int OFF_TW2 = OFF_CTL + 64;                  // float2 [16 k2][8 p1]: W_128^{p1 k2}
+    static constexpr int LDS_BYTES = OFF_TW2 + 16 * 8 * 8;        // 78912
+    static constexpr int OFF_TWN = 8 * 4 * DB_ROW_ELEMS * 8;      // row workgroup: 8 waves x 4 row buffers, then exp(+2 pi i k / 128)
+    static_assert(OFF_TWN + RB_N * 8 <= OFF_CTL, "row workgroup layout fits");
+    static_assert(OFF_CTL == FusedTile::OFF_CTL, "the control words sit where fused_join / fused_leave expect them");
+    static_assert(2 * LDS_BYTES <= 160 * 1024 && 3 * LDS_BYTES > 160 * 1024, "exactly two workgroups per CU");
+    // position pos = k1l * 128 + p of the group image, column pair cp (16 bytes)
+    static __device__ __forceinline__ int addr(int pos, int cp) { return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + cp * 16; }
+    // W_2048^{p0 (j + 1)}, j < 8: the eight entries of lane p0 are the 64 bytes of pad p0
+    static __device__ __forceinline__ int tw1_addr(int p0, int j) { return p0 * BLK_BYTES + 8 * ROW_BYTES + j * 8; }
+    static __device__ __forceinline__ int tw2_addr(int p1, int k2) { return OFF_TW2 + (k2 * 8 + p1) * 8; }
+};
+
+// the fifteen stage-1 twiddles of a lane from the eight that are stored (shared with range_pass_2048: same products)
+__device__ __forceinline__ void rb_derive_twiddles(cf (&tw)[16])
+{
+#pragma unroll
+    for (int j = 1; j < 8; j++) tw[8 + j] = cmul(tw[8], tw[j]);
+}
+
+// a QUARTER of the lane's 16 row loads (rows p0 + 128 r, r = QUARTER mod 4); plain loads: the neighbouring member asks
+// for the other half of every line at the same time and finds it in (or on its way into) the L2
+template <int QUARTER>
+__device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
+                                                  float4 (&v)[16], float2 &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int p0 = w * 16 + (l >> 2), cp = l & 3;
+    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
+    const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
+#pragma unroll
+    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<0>(rs, voff, 128 * r * RB_N * 8);
+    if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
+}
+
+__device__ __forceinline__ void fused_b_stage1_tables(const unsigned char *smem, cf (&tw)[16])
+{
+    typedef FusedTileB T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int p0 = (tid >> 6) * 16 + ((tid & 63) >> 2);
+    const unsigned char *pad = smem + T::tw1_addr(p0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) tw[j + 1] = *reinterpret_cast<const float2 *>(pad + j * 8);
+    rb_derive_twiddles(tw);
+}
+
+template <int COLUMN>
+__device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const cf (&tw)[16], cf (&g)[8])
+{
+    typedef FusedTileB T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, cp = l & 3;
+    const int p0 = w * 16 + (l >> 2);
+    const int slot = T::addr(p0, cp) + 8 * COLUMN;   // position k1*128 + p0 is 16 k1 blocks further on
+    const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
+    float wr[16];    // rows p0 + 128 r; the second half of the window mirrored: wr_c[i] = wr_c[2047 - i]
+#pragma unroll
+    for (int r = 0; r < 16; r++) wr[r] = r < 8 ? s_wr[p0 + 128 * r] : s_wr[(RB_M - 1 - 128 * r) - p0];
+    cf a[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
+        a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
+    }
+    fft16<-1>(a);
+    *reinterpret_cast<float2 *>(smem + slot) = a[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) *reinterpret_cast<float2 *>(smem + slot + k1 * 16 * T::BLK_BYTES) = cmul(a[k1], tw[k1]);
+#pragma unroll
+    for (int k1 = 8; k1 < 16; k1++) g[k1 - 8] = cmul(a[k1], tw[k1]);
+}
+
+__device__ __forceinline__ void fused_b_group1_to_lds(unsigned char *smem, const cf (&ga)[8], const cf (&gc)[8])
+{
+    typedef FusedTileB T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, cp = l & 3;
+    const int p0 = w * 16 + (l >> 2);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        *reinterpret_cast<float4 *>(smem + T::addr(j * 128 + p0, cp)) = make_float4(ga[j].x, ga[j].y, gc[j].x, gc[j].y);
+}
+
+// stage 2 of the sub-transform this wave owns (image blocks w*16 ..): ONE radix-16 item per lane -- column l & 7,
+// positions p1 + 8 r with p1 = l >> 3; a wave-instruction covers 8 positions x 64 contiguous bytes: no bank conflict
+__device__ __forceinline__ void fused_b_stage2(unsigned char *smem)
+{
+    typedef FusedTileB T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, col = l & 7, p1 = l >> 3;
+    unsigned char *base = smem + w * 16 * T::BLK_BYTES + p1 * T::ROW_BYTES + col * 8;
+    cf a[16], t[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
+    fft16<-1>(a);
+    *reinterpret_cast<float2 *>(base) = a[0];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES) = cmul(a[k2], t[k2]);
+    wave_lds_fence();
+}
+// stage 3: two radix-8 items per lane, k2 = (l >> 3) + 8 it; the 64-byte pad after every 8 positions spreads the eight
+// k2 of a wave-instruction over the banks.  Item `it` yields the gates k1 + 16 k2 + 256 k3, k3 < 4 (the rest is never read).
+__device__ __forceinline__ void fused_b_stage3(unsigned char *smem, cf (&o)[2][4])
+{
+    typedef FusedTileB T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, col = l & 7;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int k2 = (l >> 3) + 8 * it;
+        const unsigned char *base = smem + (w * 16 + k2) * T::BLK_BYTES + col * 8;
+        cf a[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::ROW_BYTES);
+        fft8<-1>(a);
+#pragma unroll
+        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
+    }
+}
+// slot row of (channel ch, gate k1 + 16 k2 + 256 k3) with k1 = w + 8 group: ch*512 + (k2 + 16 k3)*8 + w
+__device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, int ch, int col_base, const cf (&o)[2][4])
+{
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, col = l & 7;
+    const rsrc_t rd = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
+    const int voff = ((ch * 512 + (l >> 3) * 8 + w) * RB_N + col_base + col) * 8;
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
+            v2f t;
+            t.x = o[it][k3].x; t.y = o[it][k3].y;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (8 * it + 16 * k3) * 8 * RB_N * 8, 0, 0);
+        }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_2048x128(
+    const float2 *__restrict__ iq,   // [S][C][2048][128]
+    float *__restrict__ out,         // [S][1024][2]
+    float2 *pool,                    // [8][FUSED_TEAM_ELEMS]: per team ONE slot [2 channels][512][128] through which both halves go
+    FusedCtl *ctl, RangeConsts rc /* wr_c symmetric */, const float2 *__restrict__ tw_n /* exp(+2 pi i k / 128) */, int n_sectors,
+    int channels, MaTaps taps, float k_rr, float k_cal, unsigned *host_status)
+{
+    typedef FusedTileB T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_word *s_ctl = (lds_word *)(smem + T::OFF_CTL);
+    const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
+    const int gates = RB_M / 2;
+
+    const FusedSeat seat = fused_join(ctl, s_ctl);
+    const int xcc = seat.xcc, kind = seat.kind, rank = seat.rank, teams = seat.teams, trank = seat.trank;
+    if (!seat.ok || rank >= FUSED_MEMBERS) {
+        fused_leave(ctl, host_status, xcc, s_ctl);
+        return;
+    }
+    const int tasks = (n_sectors - trank + teams - 1) / teams;   // sectors of this team: one task each
+    float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
+
+    if (kind == 0) {
+        // =============================== tile member: channel rank >> 4, 8-column tile rank & 15 ===============================
+        const int ch = rank >> 4, col_base = (rank & 15) * 8;
+        auto tile_src = [&](int q) { return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
+        float4 v[16];
+        float2 wdv;
+        fused_b_tile_load<0>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<1>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<2>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<3>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
+        for (int e = tid; e < RB_M / 2; e += FUSED_THREADS) {
+            const int p0 = e >> 3, j = e & 7;
+            *reinterpret_cast<float2 *>(smem + T::tw1_addr(p0, j)) = rc.tw[(p0 * (j + 1)) & (RB_M - 1)];
+            reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
+        }
+        if (tid < 128) *reinterpret_cast<float2 *>(smem + T::tw2_addr(tid & 7, tid >> 3)) = rc.tw[(16 * (tid & 7) * (tid >> 3)) & (RB_M - 1)];
+        __syncthreads();
+        int *s_arrived = reinterpret_cast<int *>(smem + T::OFF_CTL + 56);
+        if (tid < 2) s_arrived[tid] = 0;
+        __syncthreads();
+        const FusedFlags *my_loaded0 = &ctl->loaded[0][xcc][rank], *my_loaded1 = &ctl->loaded[1][xcc][rank];
+        int failed = 0;
+#pragma unroll 1
+        for (int q = 0; q < tasks; q++) {
+            cf ga[8], gc[8];
+            {
+                cf tw[16];
+                fused_b_stage1_tables(smem, tw);
+                fused_b_stage1<0>(smem, v, wdv, tw, ga);
+                // half 1 of the previous task was stored half a stage ago: drained and counted here (see wrp_fused.h)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int last = 0;
+                if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
+                if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
+                fused_b_stage1<1>(smem, v, wdv, tw, gc);
+            }
+            __syncthreads();                    // A1: group 0 is in the image
+            const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
+            const bool more = q + 1 < tasks;
+            cf o[2][4];
+            fused_b_tile_load<0>(next, col_base, rc.wd, v, wdv, more);
+            fused_b_stage2(smem);
+            fused_b_tile_load<1>(next, col_base, rc.wd, v, wdv, more);
+            fused_b_stage3(smem, o);
+            spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1
+            __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
+            fused_b_store(mid, ch, col_base, o);
+            __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
+            fused_b_tile_load<2>(next, col_base, rc.wd, v, wdv, more);
+            fused_b_group1_to_lds(smem, ga, gc);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
+            int last = 0;
+            if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
+            if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
+            __syncthreads();                    // A3: group 1 is in the image
+            fused_b_stage2(smem);
+            fused_b_tile_load<3>(next, col_base, rc.wd, v, wdv, more);   // behind stage 2: its sixteen points + fifteen twiddles need the registers
+            fused_b_stage3(smem, o);
+            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
+            __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
+            fused_b_store(mid, ch, col_base, o);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tasks > 0 && w == 0) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)tasks);
+        if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fused_leave(ctl, host_status, xcc, s_ctl);
+    } else {
+        // =============================== row member ===============================
+        // Half g of a task: 512 slot rows per channel; member `rank` owns rows 16 rank .. + 15 of both channels, its waves
+        // 4 g .. 4 g + 3 four rows each: two passes of four 16-lane rows = (row, HH), (row, VV), (row + 1, HH), (row + 1, VV).
+        float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
+        for (int e = tid; e < RB_N; e += FUSED_THREADS) s_twn[e] = tw_n[e];
+        if (tid < 4) s_ctl[12 + tid] = 0;
+        __syncthreads();
+        const int g = w >> 2, sub = l >> 4, i = l & 15, chn = sub & 1;
+        float2 *rbuf = reinterpret_cast<float2 *>(smem) + (size_t)(w * 4 + sub) * DB_ROW_ELEMS;
+        const FusedFlags *my_stored = &ctl->stored[g][xcc][rank];
+        const rsrc_t rs = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
+        const int row0 = 16 * rank + 4 * (w & 3) + (sub >> 1);            // slot row (within a channel) of pass 0; pass 1: + 2
+#pragma unroll 1
+        for (int q = 0; q < tasks; q++) {
+#if WRP_FUSED_ROW_POLLERS
+            bool there;
+            if ((w & 3) == 0) {
+                there = spin_flags(my_stored, (unsigned)(q + 1), &ctl->status);
+                if (l == 0) s_ctl[14 + g] = there ? q + 1 : -1;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+            } else {
+                there = wait_lds_word(&s_ctl[14 + g], q + 1);
+            }
+            if (!there) break;
+#else
+            if (!spin_flags(my_stored, (unsigned)(q + 1), &ctl->status)) break;
+#endif
+            cf x0[8], x1[8];
+            const int voff = ((chn * 512 + row0) * RB_N + i) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; r++) x0[r] = buf_load_f2<AUX_SC1>(rs, voff, 16 * r * 8);
+#pragma unroll
+            for (int r = 0; r < 8; r++) x1[r] = buf_load_f2<AUX_SC1>(rs, voff + 2 * RB_N * 8, 16 * r * 8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
+            int last = 0;
+            if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
+            if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
+            float *o2 = &out[(size_t)(trank + q * teams) * gates * 2];
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int row = row0 + 2 * pass;
+                const int gate = (row >> 3) * 16 + 8 * g + (row & 7);
+                const float S = doppler_row_128<TAPS>(pass ? x1 : x0, rbuf, s_twn, taps, i);
+                const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
+                if (i == 0 && chn == 0) reflectivity_store(o2 + 2 * gate, gate, S, other, k_rr, k_cal);
+            }
+        }
+        fused_leave(ctl, host_status, xcc, s_ctl);
+    }
+}
+
+} // namespace wrp
