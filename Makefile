@@ -19,7 +19,7 @@ all: lib host oracle
 
 lib: $(LIBDIR)/libwrp.so
 
-$(LIBDIR)/libwrp.so: $(CSRC)/wrp_engine.hip $(CSRC)/wrp_kernels.h $(CSRC)/wrp_generic.h $(CSRC)/wrp_fused.h $(CSRC)/wrp_shape_b.h $(CSRC)/fft_radix.h include/wrp.h
+$(LIBDIR)/libwrp.so: $(CSRC)/wrp_engine.hip $(CSRC)/wrp_kernels.h $(CSRC)/wrp_generic.h $(CSRC)/wrp_fused.h $(CSRC)/wrp_shape_b.h $(CSRC)/wrp_fused_b.h $(CSRC)/fft_radix.h include/wrp.h
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/wrp_engine.hip
 

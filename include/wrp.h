@@ -66,7 +66,7 @@ typedef struct {
                          two-kernel range pass (8 or 16); WRP_FLAG_* below; other bits must be 0 */
 } wrp_config;
 
-/* The m = 1024, n = 512 shape runs batches of >= WRP_FUSED_MIN_SECTORS sectors as ONE persistent
+/* The m = 1024, n = 512 shape and the m = 2048, n = 128 shape run batches of >= WRP_FUSED_MIN_SECTORS sectors as ONE persistent
  * launch whose XCD teams hand the intermediate from the range FFT to the Doppler rows through
  * their L2 (csrc/wrp_fused.h); smaller batches, the slot cascade (wrp_submit) and the shapes without
  * a fused kernel run a range-pass kernel and a Doppler-pass kernel.  Both forms perform the same
@@ -94,7 +94,10 @@ typedef enum {
     WRP_STAGE_03FFT2 = 4,         /* m/2 x n complex after conj + shift + clip        (a5) */
     WRP_STAGE_04ABS = 5,          /* m/2 x n real   |.|^2                             (a6) */
     WRP_STAGE_08POW = 6,          /* m/2 x n real   MA-smoothed power                 (a7) */
-    WRP_STAGE_ROWSUM = 7          /* m/2 real       S[i]                              (a8) */
+    WRP_STAGE_ROWSUM = 7,         /* m/2 real       S[i]                              (a8) */
+    WRP_STAGE_MID = 8             /* m/2 x n complex: the half-height intermediate exactly as the production range pass of
+                                     the two-kernel path hands it to the Doppler pass (= rows < m/2 of 02FFT1; no dump
+                                     instantiation involved) */
 } wrp_stage;
 
 /* Fill *cfg with the reference's constants (m=1024, n=512, channels=2, 2 slots,
@@ -164,7 +167,9 @@ int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *ou
  * wrp_submit) with stage dumping enabled and copy stage `stage` of `channel`
  * (0 = HH, 1 = VV; VH is carried but never processed: WRP_ERR_INVALID) to host_out (sizes per
  * wrp_stage).  Dumps come from the two-kernel form, whose results the fused launch reproduces
- * bit for bit (tested).  Synchronous. */
+ * bit for bit (tested).  m = 2048, n = 128: 03FFT2_NOSHIFT .. ROWSUM and MID come from the tuned kernels of
+ * that shape, 01HAMM and 02FFT1 (all m rows, which the tuned range pass never forms) from the shape-generic
+ * kernels.  Synchronous. */
 int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_out);
 
 /* Measurement: run `iters` back-to-back wrp_process_batch_device calls on the engine's
@@ -182,10 +187,11 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
                            unsigned long long *host_stamps, size_t host_count);
 
 /* Parity of the intermediate: one fused launch over n_sectors >= WRP_FUSED_MIN_SECTORS sectors, then the
- * teams' L2-resident hand-over slots copied to host_mid[8][m/4][n] complex fp32.  Slot x holds what went
- * through it last: half 1 of the LAST channel-task of the team on XCD x (VV of the last sector that team
- * owns; with n_sectors = 8 on an 8-XCD device: sector x) -- the range-FFT gates g < m/2 with (g mod 16) >= 8,
- * gate g in slot row (g >> 4) * 8 + (g & 7).  Must equal those rows of wrp_dump_stage(02FFT1) bit for bit. */
+ * teams' L2-resident hand-over slots copied to host_mid (8 slots of 1 MiB).  Slot x holds what went through it
+ * last: half 1 -- the range-FFT gates g < m/2 with (g mod 16) >= 8, gate g in row (g >> 4) * 8 + (g & 7) -- of
+ * the LAST task of the team on XCD x (with n_sectors = 8 on an 8-XCD device: sector x):
+ *   m = 1024, n = 512: [256 rows][512] of the VV channel;  m = 2048, n = 128: [2 channels][512 rows][128].
+ * Must equal those rows of wrp_dump_stage(WRP_STAGE_MID) bit for bit. */
 int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *host_mid, size_t host_bytes);
 
 /* Introspection for harnesses. */

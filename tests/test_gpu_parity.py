@@ -203,6 +203,7 @@ def test_fused_intermediate_equals_the_dumped_range_fft(wrp, sectors):
             e.wait(0)
             fft1 = e.dump_stage(0, "02fft1", 1)[: M // 2]
             assert np.array_equal(mid[k].view(np.uint32), fft1[gates].view(np.uint32)), k
+            assert np.array_equal(fft1.view(np.uint32), e.dump_stage(0, "mid", 1).view(np.uint32))      # WRP_STAGE_MID = those rows
 
 
 def test_fused_launch_through_the_device_entry_and_check(wrp, sectors):

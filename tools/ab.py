@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--sectors", type=int, default=360)
     ap.add_argument("--rounds", type=int, default=40)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--shape", choices=["A", "B"], default="A")
+    ap.add_argument("--no-check", action="store_true", help="timing-only builds whose results are wrong on purpose")
     args = ap.parse_args()
 
     import numpy as np
@@ -35,17 +37,18 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.init()
     S = args.sectors
-    pool = np.stack([O.synthetic_sector(k) for k in range(4)])
+    m, n = (1024, 512) if args.shape == "A" else (2048, 128)
+    pool = np.stack([O.synthetic_sector(k, m, n) for k in range(4)])
     d_pool = torch.from_numpy(pool.view(np.float32).reshape(4, -1)).to(dev)
     d_iq = d_pool[torch.arange(S, device=dev) % 4].contiguous()
-    d_out = torch.empty((S, 512, 2), dtype=torch.float32, device=dev)
+    d_out = torch.empty((S, m // 2, 2), dtype=torch.float32, device=dev)
     want = O.sector(pool[1][0], pool[1][1], dtype=np.float64)
 
     engines = []
     for path in args.libs:
         B._LIB = None
         B.lib_path = (lambda p: (lambda: p))(os.path.abspath(path))     # the binding's loader, pointed at this build
-        e = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1)
+        e = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, m=m, n=n)
         e.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
         torch.cuda.synchronize()
         ok = bool(np.max(np.abs(d_out[1].cpu().numpy()[1:] - want[1:])) < 1e-3)

@@ -29,7 +29,7 @@ class WrpConfig(C.Structure):
 FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_DEBUG_FUSED_UNDERSIZED, FLAG_GENERIC_KERNELS = 0x400, 0x800, 0x4000, 0x8000
 FUSED_MIN_SECTORS = 8
 
-STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7}
+STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7, "mid": 8}
 
 
 def STAGE_SHAPES(m, n):
@@ -37,7 +37,7 @@ def STAGE_SHAPES(m, n):
         "01hamm": ((m, n), np.complex64), "02fft1": ((m, n), np.complex64),
         "03fft2-noshift": ((m // 2, n), np.complex64), "03fft2": ((m // 2, n), np.complex64),
         "04abs": ((m // 2, n), np.float32), "08pow": ((m // 2, n), np.float32),
-        "rowsum": ((m // 2,), np.float32),
+        "rowsum": ((m // 2,), np.float32), "mid": ((m // 2, n), np.complex64),
     }
 
 

@@ -20,6 +20,7 @@
 #include "wrp_generic.h"
 #include "wrp_fused.h"
 #include "wrp_shape_b.h"
+#include "wrp_fused_b.h"
 
 #define WRP_VERSION_STRING "wrp-amd 0.1 (gfx950)"
 
@@ -162,7 +163,8 @@ void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mi
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
-    if (h->tuned_b && !dump) {
+    // shape B: the tuned kernel, except for the two dumps that need all m rows (it only ever forms the gates < m/2)
+    if (h->tuned_b && !(dump && (dump->hamm || dump->fft1))) {
         const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
         const int total = n_sectors * 2 * (wrp::RB_N / 16), grid = std::min(total, h->n_cus);
         hipLaunchKernelGGL(wrp::range_pass_2048, dim3(grid), dim3(wrp::RangeTileB::THREADS), wrp::RangeTileB::LDS_BYTES, st, d_iq,
@@ -223,15 +225,15 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
-    if (h->tuned_b && !dump) {
+    if (h->tuned_b && !(dump && (dump->hamm || dump->fft1))) {
         const wrp_config &c = h->cfg;
         const dim3 grid(c.m / 2 / (wrp::DB_WAVES * 2), n_sectors), block(wrp::DB_WAVES * 64);
-        if (h->taps_pad == 7)
-            hipLaunchKernelGGL(wrp::doppler_pass_128<7>, grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps,
-                               c.k_range_resolution, c.k_calibration);
-        else
-            hipLaunchKernelGGL(wrp::doppler_pass_128<9>, grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps,
-                               c.k_range_resolution, c.k_calibration);
+#define WRP_DOPPLER_B(TAPS, DUMP)                                                                                    \
+    hipLaunchKernelGGL((wrp::doppler_pass_128<TAPS, DUMP>), grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps, \
+                       c.k_range_resolution, c.k_calibration, dump ? *dump : none)
+        if (h->taps_pad == 7) { if (dump) WRP_DOPPLER_B(7, true); else WRP_DOPPLER_B(7, false); }
+        else { if (dump) WRP_DOPPLER_B(9, true); else WRP_DOPPLER_B(9, false); }
+#undef WRP_DOPPLER_B
         return;
     }
     if (!h->tuned) {
@@ -269,6 +271,16 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
     // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
+    if (h->tuned_b) {
+#define WRP_FUSED_B(TAPS)                                                                                             \
+    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS>), dim3(grid), dim3(wrp::FUSED_THREADS), wrp::FusedTileB::LDS_BYTES, st, \
+                       d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,           \
+                       c.k_range_resolution, c.k_calibration, h->d_status + slot)
+        if (h->taps_pad == 7) WRP_FUSED_B(7); else WRP_FUSED_B(9);
+#undef WRP_FUSED_B
+        HIP_TRY(h, hipGetLastError());
+        return WRP_OK;
+    }
 #define WRP_FUSED(TAPS, STAMPS)                                                                                       \
     hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
@@ -430,7 +442,11 @@ int create_impl(wrp_engine *h)
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_2048),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
     // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
-    h->fused = h->tuned && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
+    h->fused = (h->tuned || h->tuned_b) && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<7>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<9>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES));
     h->fused_armed = h->fused;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
     if ((c.flags & 0xff) == 0) h->range_tcols = h->persist ? 16 : 8;   // best measured tile for each form
@@ -471,6 +487,11 @@ int create_impl(wrp_engine *h)
 
     std::vector<float> wr, wd;
     make_window(c.m, c.n, wr, wd);
+    // The Hamming window is symmetric, w(i) = w(m - 1 - i); the fused launch of shape B keeps only its first half in LDS.
+    // As computed (double, rounded to float) the two halves may differ in the last bit of a few entries: the second half
+    // is MADE the mirror of the first, for every kernel of this shape, so that they all see the same values.
+    if (h->tuned_b)
+        for (int i = c.m / 2; i < c.m; i++) wr[i] = wr[c.m - 1 - i];
     std::vector<float2> twm(c.m), twn(c.n);
     for (int k = 0; k < c.m; k++) twm[k] = make_float2((float)std::cos(2 * M_PI * k / c.m), (float)-std::sin(2 * M_PI * k / c.m));
     for (int k = 0; k < c.n; k++) twn[k] = make_float2((float)std::cos(2 * M_PI * k / c.n), (float)std::sin(2 * M_PI * k / c.n));
@@ -739,7 +760,16 @@ int wrp_dump_stage(wrp_handle h, int slot, int stage, int channel, void *host_ou
     case WRP_STAGE_03FFT2_NOSHIFT: case WRP_STAGE_03FFT2: bytes = sizeof(float2) * (size_t)(c.m / 2) * c.n; break;
     case WRP_STAGE_04ABS: case WRP_STAGE_08POW: bytes = sizeof(float) * (size_t)(c.m / 2) * c.n; break;
     case WRP_STAGE_ROWSUM: bytes = sizeof(float) * (size_t)(c.m / 2); break;
+    case WRP_STAGE_MID: bytes = sizeof(float2) * (size_t)(c.m / 2) * c.n; break;
     default: return WRP_ERR_INVALID;
+    }
+    if (stage == WRP_STAGE_MID) {   // what the production range pass hands to the Doppler pass: no dump instantiation involved
+        HIP_TRY(h, hipSetDevice(h->device));
+        int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr);
+        if (rc != WRP_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(host_out, s.d_mid + (size_t)channel * (c.m / 2) * c.n, bytes, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipStreamSynchronize(s.stream));
+        return WRP_OK;
     }
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->dump_bytes < bytes) {
@@ -863,7 +893,7 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
 int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *host_mid, size_t host_bytes)
 {
     if (!h || !d_iq || !d_out || !host_mid || n_sectors < WRP_FUSED_MIN_SECTORS) return WRP_ERR_INVALID;
-    if (!h->tuned) return WRP_ERR_UNSUPPORTED;
+    if (!h->tuned && !h->tuned_b) return WRP_ERR_UNSUPPORTED;
     const size_t bytes = sizeof(float2) * wrp::FUSED_TEAM_ELEMS * 8;
     if (host_bytes < bytes) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

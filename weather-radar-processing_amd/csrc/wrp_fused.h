@@ -71,10 +71,13 @@ constexpr int FUSED_STAMP_TASKS = 16;
 // the time at which it NOTICES a half: the tile members wait at their look for the slowest row wave of the team, and every
 // tenth of a microsecond added to a notice is added to the task (a poller costs 6 %).
 #ifndef WRP_FUSED_POLL_SLEEP
-#define WRP_FUSED_POLL_SLEEP 4
+#define WRP_FUSED_POLL_SLEEP 1
 #endif
 #ifndef WRP_FUSED_WAIT_SLEEP
 #define WRP_FUSED_WAIT_SLEEP 16      // (poller form only) s_sleep units of a row wave that waits for its half's poller
+#endif
+#ifndef WRP_FUSED_ROW_SPLIT
+#define WRP_FUSED_ROW_SPLIT 1       // 1: every row wave serves both halves, one row of each; 0: four waves per half, two rows each
 #endif
 #ifndef WRP_FUSED_ROW_POLLERS
 #define WRP_FUSED_ROW_POLLERS 0     // 1: one wave per half polls the L2 and wakes the other three (measured slower: above)
@@ -352,19 +355,27 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;   // position w*64 of this lane's column
+    // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place; two items per lane, p1 = (l >> 4) + 4 it.
+    // The reads of BOTH items and the first item's twiddles go out in one batch; the second item's twiddles are read
+    // while the first item is transformed: two LDS round trips stand in the open instead of four.
+    const int pa = l >> 4, pb = pa + 4;
+    cf a[8], b[8], t[8];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {   // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
-        const int p1 = (l >> 4) + 4 * it;
-        cf a[8], t[8];   // the seven twiddles in one batch with the data, not one LDS round trip each
+    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + pa * T::ROW_BYTES);
 #pragma unroll
-        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
+    for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(pa, k2));
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
-        fft8<-1>(a);
-        *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
+    for (int r = 0; r < 8; r++) b[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + pb * T::ROW_BYTES);
+    fft8<-1>(a);
+    *reinterpret_cast<float2 *>(base + pa * T::ROW_BYTES) = a[0];
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t[k2]);
-    }
+    for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + pa * T::ROW_BYTES) = cmul(a[k2], t[k2]);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(pb, k2));
+    fft8<-1>(b);
+    *reinterpret_cast<float2 *>(base + pb * T::ROW_BYTES) = b[0];
+#pragma unroll
+    for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + pb * T::ROW_BYTES) = cmul(b[k2], t[k2]);
     wave_lds_fence();
 }
 __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
@@ -375,16 +386,19 @@ __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
+    // stage 3: radix 8 over the 8 contiguous positions k2*8 + r, k2 = (l >> 4) + 4 it; both items read in one batch
+    const int ka = l >> 4, kb = ka + 4;
+    cf a[8], b[8];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {   // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
-        const int k2 = (l >> 4) + 4 * it;
-        cf a[8];
+    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + ka * T::BLK_BYTES + r * T::ROW_BYTES);
 #pragma unroll
-        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
-        fft8<-1>(a);
+    for (int r = 0; r < 8; r++) b[r] = *reinterpret_cast<const float2 *>(base + kb * T::BLK_BYTES + r * T::ROW_BYTES);
+    fft8<-1>(a);
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
-    }
+    for (int k3 = 0; k3 < 4; k3++) o[0][k3] = a[k3];
+    fft8<-1>(b);
+#pragma unroll
+    for (int k3 = 0; k3 < 4; k3++) o[1][k3] = b[k3];
 }
 __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
 {
@@ -652,9 +666,40 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         doppler_twiddles_to_lds(s_twn, tw_n, tid, FUSED_THREADS);
-        if (tid < 4) s_ctl[12 + tid] = 0;   // 12, 13: arrival counts of the halves; 14, 15: tasks seen published, per half
+        if (tid < 4) s_ctl[12 + tid] = 0;   // 12, 13: arrival counts of the halves; 14, 15: (poller form) tasks seen published, per half
         __syncthreads();
         const DumpPtrs nodump{};
+#if WRP_FUSED_ROW_SPLIT
+        // Every wave serves BOTH halves, one row of each: a half is then loaded by eight waves with 8 requests each instead
+        // of four waves with 16 -- the row loads sit in the hand-over chain the tile members wait for at their looks.  A wave
+        // has finished its row of one half well before the other half is published (a row is ~2 us of the ~10 us task).
+        const int r0 = rank * 8 + w;                            // slot row of this wave's gate in either half
+        float s_hh[2] = {0.f, 0.f};                             // HH row sums of its two gates, waiting for the VV task
+#pragma unroll 1
+        for (int q = 0; q < tasks; q++) {
+            bool there = true;
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int gate = rank * 16 + 8 * g + w;
+                if (g == 0) stamp(q, 0);
+                there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
+                if (!there) break;                              // status is set: the launch is void
+                if (g == 0) stamp(q, 1);
+                cf x[8];
+                doppler_load_row<AUX_SC1>(mid + (size_t)r0 * n, l, x);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row in registers: the slot may be overwritten
+                int last = 0;
+                if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
+                if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
+                if (g == 0) stamp(q, 2);
+                const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
+                if (g == 0) stamp(q, 3);
+                if ((q & 1) == 0) s_hh[g] = s;
+                else if (l == 0) reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh[g], s, k_rr, k_cal);
+            }
+            if (!there) break;
+        }
+#else
         const int g = w >> 2;                                  // this wave's half
         const int g0 = rank * 16 + 8 * g + 2 * (w & 3);        // its gates g0, g0 + 1
         const FusedFlags *my_stored = &ctl->stored[g][xcc][rank];
@@ -697,6 +742,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 reflectivity_store(o2 + 2, g0 + 1, s_hh1, s1, k_rr, k_cal);
             }
         }
+#endif
         flush_stamps();
         fused_leave(ctl, host_status, xcc, s_ctl);
     }

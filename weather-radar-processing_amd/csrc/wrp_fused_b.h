@@ -11,14 +11,14 @@
 //   * 2048 = 16 x 16 x 8: stage 1 (registers) radix 16 over rows p0 + 128 r, stage 2 (LDS, wave-local) radix 16 over
 //     positions p1 + 8 r of the sub-transform the wave owns, stage 3 radix 8; the sixteen 128-point sub-transforms go
 //     through LDS in two groups of eight as there, the gates of group g are those with (gate mod 16) in [8 g, 8 g + 8):
-//     half g of the slot, [2 channels][512 rows][128] complex, row (gate >> 4) * 8 + (gate & 7);
+//     half g of the slot (layout: fused_b_store);
 //   * LDS: the group image [8 k1][16 blocks of 8 positions x 64 B + 64 B of padding] is 72 KiB as there; its 128 pads
 //     hold the stage-1 twiddles W_2048^{p0 k1} for k1 = 1 .. 8 only (one pad per p0) -- k1 = 9 .. 15 are the products
 //     W^{8 p0} W^{(k1 - 8) p0} (seven complex multiplies per lane and tile; range_pass_2048 forms them the same way,
 //     so the two forms stay bit-identical) -- and the range window is kept as its first half (it is symmetric: the
 //     engine stores wr_c[i] = wr_c[m - 1 - i] exactly): 78,912 bytes, two workgroups per CU;
 //   * a row wave transforms FOUR rows at a time (16 lanes per row, 128 = 8 x 4 x 4: doppler_row_128), the HH and the
-//     VV row of two gates, so Zdb and Zdr leave with the task that produced them.
+//     VV row of two gates, so Zdb and Zdr leave with the task that produced them; every wave serves both halves.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,8 +52,14 @@ __device__ __forceinline__ void rb_derive_twiddles(cf (&tw)[16])
     for (int j = 1; j < 8; j++) tw[8 + j] = cmul(tw[8], tw[j]);
 }
 
-// a QUARTER of the lane's 16 row loads (rows p0 + 128 r, r = QUARTER mod 4); plain loads: the neighbouring member asks
-// for the other half of every line at the same time and finds it in (or on its way into) the L2
+// a QUARTER of the lane's 16 row loads (rows p0 + 128 r, r = QUARTER mod 4).  The neighbouring member asks for the other
+// half of every 128-byte line at the same time and finds it in (or on its way into) the L2.  Non-temporal like the
+// 1024 x 512 launch's input: beside a PLAIN stream the rewritten slot does not stay in the L2 (83 % of the intermediate
+// was written back: WRITE_SIZE 1.75 MB per sector, profiles/r03/fused_b_input_policy.log).
+#ifndef WRP_FUSED_B_INPUT_AUX
+#define WRP_FUSED_B_INPUT_AUX 2   /* AUX_NT */
+#endif
+constexpr int FUSED_B_INPUT_AUX = WRP_FUSED_B_INPUT_AUX;
 template <int QUARTER>
 __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                   float4 (&v)[16], float2 &wdv, bool valid)
@@ -62,10 +68,21 @@ __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-unif
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int p0 = w * 16 + (l >> 2), cp = l & 3;
+#ifdef WRP_EXP_B_NOLOAD
+    valid = false;
+#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
+#ifdef WRP_EXP_B_FULLLINE   // timing only: whole 128-byte lines, the two members of a pair take alternate rows
+    const int pp = w * 8 + (l >> 3), c8 = l & 7, par = (col_base >> 3) & 1;
+    const int voffx = ((2 * pp + par) * RB_N + (col_base & ~15) + c8 * 2) * 8;
+#pragma unroll
+    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voffx, 128 * r * RB_N * 8);
+    if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
+    return;
+#endif
     const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
 #pragma unroll
-    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<0>(rs, voff, 128 * r * RB_N * 8);
+    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * r * RB_N * 8);
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
@@ -165,22 +182,32 @@ __device__ __forceinline__ void fused_b_stage3(unsigned char *smem, cf (&o)[2][4
         for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
     }
 }
-// slot row of (channel ch, gate k1 + 16 k2 + 256 k3) with k1 = w + 8 group: ch*512 + (k2 + 16 k3)*8 + w
+// The slot of shape B: [2 channels][256 pair rows Q][16 tiles][2 gates][8 columns] complex.  A tile member holds only 8
+// columns = 64 bytes of a gate's row, and a store that covers half a 128-byte line is written THROUGH by the L2 (first
+// form, one gate per slot row: 83 % of the intermediate went out to HBM, 1.75 MB per sector of WRITE_SIZE): so the two
+// gates k2 = 2 a, 2 a + 1 of a store instruction's lane pairs share a line -- 16 lanes x 8 bytes, whole lines only -- and
+// a row wave reads both of them (and both channels) in the same pass.  Pair row Q of half g:
+//   Q = ((k3 * 2 + it) * 4 + (k2l >> 1)) * 8 + (k1 - 8 g)      with k2 = k2l + 8 it, k2l < 8
+//   gate(Q, pb) = 8 g + (Q & 7) + 16 * (2 * ((Q >> 3) & 3) + pb + 8 * ((Q >> 5) & 1)) + 256 * (Q >> 6),   pb = k2l & 1
+__device__ __forceinline__ int fused_b_gate(int g, int Q, int pb)
+{
+    return 8 * g + (Q & 7) + 16 * (2 * ((Q >> 3) & 3) + pb + 8 * ((Q >> 5) & 1)) + 256 * (Q >> 6);
+}
 __device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, int ch, int col_base, const cf (&o)[2][4])
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, col = l & 7;
+    const int w = tid >> 6, l = tid & 63, c8 = l & 7, k2l = l >> 3;
     const rsrc_t rd = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
-    const int voff = ((ch * 512 + (l >> 3) * 8 + w) * RB_N + col_base + col) * 8;
+    const int voff = ((ch * 256 + (k2l >> 1) * 8 + w) * 16 + (col_base >> 3)) * 128 + (k2l & 1) * 64 + c8 * 8;
 #pragma unroll
     for (int it = 0; it < 2; it++)
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) {   // row offset in the VGPR, soffset 0: see buf_store_f4
             v2f t;
             t.x = o[it][k3].x; t.y = o[it][k3].y;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (8 * it + 16 * k3) * 8 * RB_N * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (k3 * 2 + it) * 4 * 8 * 16 * 128, 0, 0);
         }
 }
 
@@ -276,51 +303,42 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         fused_leave(ctl, host_status, xcc, s_ctl);
     } else {
         // =============================== row member ===============================
-        // Half g of a task: 512 slot rows per channel; member `rank` owns rows 16 rank .. + 15 of both channels, its waves
-        // 4 g .. 4 g + 3 four rows each: two passes of four 16-lane rows = (row, HH), (row, VV), (row + 1, HH), (row + 1, VV).
+        // Every wave serves both halves: per half ONE pass over pair row Q = 8 rank + w -- four 16-lane rows: the two
+        // gates of the pair x {HH, VV} -- whole 128-byte lines per load instruction; Zdb / Zdr of both gates leave at once.
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         for (int e = tid; e < RB_N; e += FUSED_THREADS) s_twn[e] = tw_n[e];
         if (tid < 4) s_ctl[12 + tid] = 0;
         __syncthreads();
-        const int g = w >> 2, sub = l >> 4, i = l & 15, chn = sub & 1;
+        const int sub = l >> 4, i = l & 15, pb = sub & 1, chn = sub >> 1;
         float2 *rbuf = reinterpret_cast<float2 *>(smem) + (size_t)(w * 4 + sub) * DB_ROW_ELEMS;
-        const FusedFlags *my_stored = &ctl->stored[g][xcc][rank];
         const rsrc_t rs = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
-        const int row0 = 16 * rank + 4 * (w & 3) + (sub >> 1);            // slot row (within a channel) of pass 0; pass 1: + 2
+        const int Q = 8 * rank + w;
+        const int voff = (chn * 256 + Q) * 2048 + (i >> 3) * 128 + pb * 64 + (i & 7) * 8;   // element j = i + 16 r: tile 2 r + (i >> 3)
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
-#if WRP_FUSED_ROW_POLLERS
-            bool there;
-            if ((w & 3) == 0) {
-                there = spin_flags(my_stored, (unsigned)(q + 1), &ctl->status);
-                if (l == 0) s_ctl[14 + g] = there ? q + 1 : -1;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
-            } else {
-                there = wait_lds_word(&s_ctl[14 + g], q + 1);
-            }
-            if (!there) break;
-#else
-            if (!spin_flags(my_stored, (unsigned)(q + 1), &ctl->status)) break;
-#endif
-            cf x0[8], x1[8];
-            const int voff = ((chn * 512 + row0) * RB_N + i) * 8;
-#pragma unroll
-            for (int r = 0; r < 8; r++) x0[r] = buf_load_f2<AUX_SC1>(rs, voff, 16 * r * 8);
-#pragma unroll
-            for (int r = 0; r < 8; r++) x1[r] = buf_load_f2<AUX_SC1>(rs, voff + 2 * RB_N * 8, 16 * r * 8);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
-            int last = 0;
-            if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
-            if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
+            bool there = true;
             float *o2 = &out[(size_t)(trank + q * teams) * gates * 2];
 #pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
-                const int row = row0 + 2 * pass;
-                const int gate = (row >> 3) * 16 + 8 * g + (row & 7);
-                const float S = doppler_row_128<TAPS>(pass ? x1 : x0, rbuf, s_twn, taps, i);
-                const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
+            for (int g = 0; g < 2; g++) {
+                there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
+                if (!there) break;                              // status is set: the launch is void
+                cf x[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_SC1>(rs, voff, r * 256);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
+                int last = 0;
+                if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
+                if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
+                const int gate = fused_b_gate(g, Q, pb);
+#ifdef WRP_EXP_B_NOROW
+                const float S = x[0].x + x[7].y;
+#else
+                const float S = doppler_row_128<TAPS>(x, rbuf, s_twn, taps, i);
+#endif
+                const float other = __shfl(S, (l + 32) & 63);     // the VV row sum sits 32 lanes above the HH one
                 if (i == 0 && chn == 0) reflectivity_store(o2 + 2 * gate, gate, S, other, k_rr, k_cal);
             }
+            if (!there) break;
         }
         fused_leave(ctl, host_status, xcc, s_ctl);
     }

@@ -1,7 +1,8 @@
 // wrp_shape_b.h -- tuned kernels for BASELINE.json configs[4]: m = 2048 range cells x n = 128 pulses
 // (the reference cannot run this shape at all: __clip_v2<<<2, m>>> needs m <= 1024 and d_ma[512],
-// rpv2.cu:84,145-148).  Same chain and semantics as wrp_kernels.h; stage dumps of this shape come from
-// the generic kernels (wrp_generic.h), against which these are tested.
+// rpv2.cu:84,145-148).  Same chain and semantics as wrp_kernels.h.  Stage dumps: the Doppler stages (03 .. rowsum)
+// and the half-height intermediate (WRP_STAGE_MID) come from THESE kernels; 01hamm and 02fft1 (all m rows, which
+// range_pass_2048 never forms) from the generic kernels of wrp_generic.h, against which these are tested too.
 //
 //   range_pass_2048   : a2 + a3.  2048 = 16 x 16 x 8 over the positions p of a column, one 1024-thread
 //                       workgroup per CU walking 16-column tiles (whole 128-byte lines) with the next
@@ -50,9 +51,24 @@ __device__ __forceinline__ void rb_tile_load(const float2 *src /* wave-uniform *
     wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
+// The lane's fifteen stage-1 twiddles W_2048^{p0 k1}: k1 = 1 .. 8 come from the table, k1 = 9 .. 15 are the products
+// W^{8 p0} W^{(k1 - 8) p0} -- the fused launch (wrp_fused_b.h) has LDS for eight per lane only, and the two forms perform
+// the same arithmetic so that their results are bit-identical.  One batch of reads in front of the first butterfly.
+__device__ __forceinline__ void rb_stage1_tables(const unsigned char *smem, cf (&tw)[16])
+{
+    typedef RangeTileB T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int p0 = (tid >> 6) * 8 + ((tid & 63) >> 3);
+#pragma unroll
+    for (int k1 = 1; k1 <= 8; k1++) tw[k1] = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RB_M - 1)));
+#pragma unroll
+    for (int j = 1; j < 8; j++) tw[8 + j] = cmul(tw[8], tw[j]);
+}
+
 // stage 1 of ONE of the lane's two columns: window, radix 16, twiddle; k1 < 8 to LDS, k1 >= 8 kept
 template <int COLUMN>
-__device__ __forceinline__ void rb_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&g)[8])
+__device__ __forceinline__ void rb_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const cf (&tw)[16], cf (&g)[8])
 {
     typedef RangeTileB T;
     int tid = threadIdx.x;
@@ -63,22 +79,16 @@ __device__ __forceinline__ void rb_stage1(unsigned char *smem, const float4 (&v)
     const int slot = T::addr(p0, cp) + 8 * COLUMN;   // position k1*128 + p0 is 16 k1 blocks further on
     cf a[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < 16; r++) {   // (a batch of the sixteen window reads costs this kernel 19 spilled registers)
         const float wgt = s_wr[p0 + 128 * r] * (COLUMN ? wdv.y : wdv.x);
         a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
     }
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RB_M - 1)));
-        *reinterpret_cast<float2 *>(smem + slot + k1 * 16 * T::BLK_BYTES) = cmul(a[k1], t);
-    }
+    for (int k1 = 1; k1 < 8; k1++) *reinterpret_cast<float2 *>(smem + slot + k1 * 16 * T::BLK_BYTES) = cmul(a[k1], tw[k1]);
 #pragma unroll
-    for (int k1 = 8; k1 < 16; k1++) {
-        const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RB_M - 1)));
-        g[k1 - 8] = cmul(a[k1], t);
-    }
+    for (int k1 = 8; k1 < 16; k1++) g[k1 - 8] = cmul(a[k1], tw[k1]);
 }
 
 __device__ __forceinline__ void rb_group1_to_lds(unsigned char *smem, const cf (&ga)[8], const cf (&gc)[8])
@@ -108,7 +118,7 @@ __device__ __forceinline__ void rb_stage2(unsigned char *smem)
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(base) = a[0];
 #pragma unroll
-    for (int k2 = 1; k2 < 16; k2++) {
+    for (int k2 = 1; k2 < 16; k2++) {   // twiddles at their points of use: the next tile's 64 registers are in flight here
         const cf t = *reinterpret_cast<const float2 *>(smem + T::tw_addr((16 * p1 * k2) & (RB_M - 1)));
         *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES) = cmul(a[k2], t);
     }
@@ -170,9 +180,13 @@ __global__ __launch_bounds__(RangeTileB::THREADS, 4) void range_pass_2048(
         float2 *dst = mid + ((size_t)sec * 2 + ch) * (RB_M / 2) * (size_t)RB_N;
         const int col_base = tile * 16;
         cf ga[8], gc[8];
-        rb_stage1<0>(smem, v, wdv, ga);
-        __builtin_amdgcn_sched_barrier(0);
-        rb_stage1<1>(smem, v, wdv, gc);
+        {
+            cf tw[16];
+            rb_stage1_tables(smem, tw);
+            rb_stage1<0>(smem, v, wdv, tw, ga);
+            __builtin_amdgcn_sched_barrier(0);
+            rb_stage1<1>(smem, v, wdv, tw, gc);
+        }
         __syncthreads();                 // group 0 in the image
         rb_stage2(smem);
         __syncthreads();
@@ -210,8 +224,10 @@ __device__ __forceinline__ float row16_sum(float v)
 
 // a4 .. a8 of one row held by 16 lanes (lane i of the row: j = i + 16 r); returns S in every lane of the row.
 // buf: this row's LDS buffer; tw: exp(+2 pi i k / 128).
-template <int TAPS>
-__device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const float2 *tw, const MaTaps &taps, int i)
+// DUMP: the stage dumps of wrp_dump_stage from THESE kernels (gate, do_dump, dump as in doppler_row)
+template <int TAPS, bool DUMP = false>
+__device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const float2 *tw, const MaTaps &taps, int i, int gate = 0,
+                                                 bool do_dump = false, const DumpPtrs &dump = DumpPtrs{})
 {
     float *fbuf = reinterpret_cast<float *>(buf);
     asm volatile("" : "+v"(i));
@@ -276,7 +292,9 @@ __device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const 
                 const int k = k1 + 8 * k2 + 32 * k3;
                 const int j = (k + RB_N / 2) & (RB_N - 1);
                 cf z = v[4 * it + k3];
+                if (DUMP && do_dump && dump.noshift) dump.noshift[(size_t)gate * RB_N + k] = make_float2(z.x, -z.y);   // before the final conj
                 if (j >= RB_N - 2) z = make_float2(0.f, 0.f);
+                if (DUMP && do_dump && dump.fft2) dump.fft2[(size_t)gate * RB_N + j] = z;
                 fbuf[db_fidx(j)] = fmaf(z.y, z.y, z.x * z.x);
             }
         }
@@ -293,25 +311,31 @@ __device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const 
         a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
         a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
     }
+    if (DUMP && do_dump && dump.abs2) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * RB_N + 8 * i + u] = a[8 + u];
+    }
     float part = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         float p = 0.f;
 #pragma unroll
         for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
+        if (DUMP && do_dump && dump.pow) dump.pow[(size_t)gate * RB_N + 8 * i + u] = p;
         part += p;
     }
     const float S = row16_sum(part);
+    if (DUMP && do_dump && dump.rowsum && i == 0) dump.rowsum[gate] = S;
     wave_lds_fence();
     return S;
 }
 
-template <int TAPS>
+template <int TAPS, bool DUMP = false>
 __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     const float2 *__restrict__ mid,  // [S][2][gates][128]
     float *__restrict__ out,         // [S][gates][2]
     const float2 *__restrict__ tw,   // [128] exp(+2 pi i k / 128)
-    int gates, MaTaps taps, float k_rr, float k_cal)
+    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump = DumpPtrs{})
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DB_WAVES * 4][DB_ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) float2 s_tw[RB_N];
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_NT>(rs, voff, 16 * r * 8);
     for (int e = threadIdx.x; e < RB_N; e += DB_WAVES * 64) s_tw[e] = tw[e];
     __syncthreads();
-    const float S = doppler_row_128<TAPS>(x, lds[w * 4 + sub], s_tw, taps, i);
+    const float S = doppler_row_128<TAPS, DUMP>(x, lds[w * 4 + sub], s_tw, taps, i, gate, DUMP && dump.channel == ch && sec == 0, dump);
     const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
     if (i == 0 && ch == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal);
 }
