@@ -4,6 +4,9 @@
 #   make / make all   libwrp.so (C ABI + HIP kernels), host objects, rpv2 binary, oracle
 #   make lib          weather-radar-processing_amd/lib/libwrp.so only
 #   make oracle       oracle/liboracle.so (+ oracle/_ref when /root/reference exists)
+#   make process      the reference's commented alternative entry point (Makefile:3 there: `process`, the UDP program of
+#                     gpu_1fp_streamcasc.cu / read_single.cc): the same binary as rpv2, under that name -- run it as
+#                     `process 4 --in udp:19001 --out udp:19002,19003` (its defaults)
 #   make clean
 
 HIPCC    ?= /opt/rocm/bin/hipcc
@@ -15,7 +18,7 @@ LIBDIR   := $(PKG)/lib
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=off -fno-slp-vectorize
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -Wall
 
-all: lib host oracle
+all: lib host oracle process
 
 lib: $(LIBDIR)/libwrp.so
 
@@ -26,6 +29,9 @@ $(LIBDIR)/libwrp.so: $(CSRC)/wrp_engine.hip $(CSRC)/wrp_kernels.h $(CSRC)/wrp_ge
 host:
 	@if [ -f $(HOST)/Makefile ]; then $(MAKE) -C $(HOST); fi
 
+process: host
+	ln -sf rpv2 $(HOST)/process
+
 oracle:
 	$(MAKE) -C oracle
 	@if [ -d /root/reference ]; then $(MAKE) -C oracle ref; fi
@@ -35,4 +41,4 @@ clean:
 	$(MAKE) -C oracle clean
 	@if [ -f $(HOST)/Makefile ]; then $(MAKE) -C $(HOST) clean; fi
 
-.PHONY: all lib host oracle clean
+.PHONY: all lib host oracle process clean

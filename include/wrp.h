@@ -141,6 +141,16 @@ int wrp_wait(wrp_handle h, int slot);
  * (rpv2.cu:736, :626-629): (*zdb_zdr)[gate*2 + 0] = Zdb, [gate*2 + 1] = Zdr. */
 int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr);
 
+/* Egress framing on the GPU.  The reference converts every product to big-endian floats on the CPU
+ * and prepends the header (rpv2.cu:631-661: [sector BE16][elevation BE16][m/2 BE floats], topics "B" = Zdb and "C" = Zdr;
+ * read_single.cc:510-520: [sector BE16][m/2 BE floats] on UDP 19002 / 19003).  Here the Doppler pass writes both products
+ * planar and big-endian behind their header and the slot's D2H copy delivers them wire-ready: *frame points INTO the
+ * pinned frame table (which = 0: Zdb, 1: Zdr; with_elevation selects the 4-byte or the 2-byte header; *bytes = 4*(m/2)
+ * + 4 or + 2) -- send it as it is.  Valid after wrp_wait of the slot that processed (sector, elevation), until that
+ * pair is submitted again. */
+int wrp_result_frame(wrp_handle h, int sector, int elevation, int which, int with_elevation, const unsigned char **frame,
+                     size_t *bytes);
+
 /* Kernel-only entries (device-resident in and out; used for roofline timing and by
  * callers that already hold the IQ block on the GPU).
  * d_iq : [n_sectors][channels][m][n] complex fp32;  d_out : [n_sectors][m/2][2] fp32.

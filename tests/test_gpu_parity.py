@@ -385,3 +385,34 @@ def test_call_order_errors(engine, sectors):
     engine.wait(0)
     assert engine.lib.wrp_submit(engine.handle, 0, 99, 0) == -1  # sector outside the result table
     assert engine.lib.wrp_submit(engine.handle, 7, 0, 0) == -1   # no such slot
+
+
+def test_products_framed_on_the_gpu_are_byte_exact(wrp, oracle, sectors):
+    """the Doppler pass writes Zdb and Zdr planar and BIG-ENDIAN behind their header, the slot's D2H copy
+    delivers them wire-ready and wrp_result_frame hands out the bytes where they lie.  Byte-exact against the oracle's
+    framing of the same results (rpv2.cu:631-661: [sector BE16][elevation BE16][BE floats]; read_single.cc:510-520:
+    [sector BE16][BE floats]) -- 1024 x 512, the tuned 2048 x 128 kernels, a generic shape, planar and wire-format ingest."""
+    for m, n, flags in ((M, N, 0), (2048, 128, 0), (256, 64, 0)):
+        iq = sectors[1] if (m, n) == (M, N) else oracle.synthetic_sector(3, m, n)
+        with wrp.Engine(device=0, m=m, n=n, n_slots=2, n_sectors=700, n_elevations=3, flags=flags) as e:
+            for slot, (sector, elev) in enumerate(((517, 2), (3, 0))):
+                e.slot_array(slot)[:] = iq * np.float32(1 + slot)
+                e.submit(slot, sector, elev)
+            for slot, (sector, elev) in enumerate(((517, 2), (3, 0))):
+                e.wait(slot)
+                res = e.result(sector, elev).copy()
+                for which in (0, 1):
+                    for with_elev in (True, False):
+                        got = e.result_frame(sector, elev, which, with_elev)
+                        want = oracle.frame_result(res, sector, elev, which, with_elev)
+                        assert got.tobytes() == want.tobytes(), (m, n, sector, which, with_elev)
+            assert e.lib.wrp_result_frame(e.handle, 700, 0, 0, 1, None, None) == -1
+    # wire-format ingest frames the same way
+    hh, vv = sectors[2][0], sectors[2][1]
+    w = np.zeros((M * N, 6), dtype=">i2")
+    w[:, 0], w[:, 1], w[:, 2], w[:, 3] = hh.real.ravel(), hh.imag.ravel(), vv.real.ravel(), vv.imag.ravel()
+    with wrp.Engine(device=0, n_slots=1, n_sectors=4, n_elevations=1) as e:
+        e.raw_slot_array(0)[:] = np.frombuffer(w.tobytes(), np.uint8)
+        e.submit_raw(0, 2, 0)
+        e.wait(0)
+        assert e.result_frame(2, 0, 1, False).tobytes() == oracle.frame_result(e.result(2, 0), 2, 0, 1, False).tobytes()

@@ -116,6 +116,8 @@ def load_library():
     lib.wrp_debug_fused_stamps.argtypes = [vp, vp, i, vp, vp, C.c_size_t]
     lib.wrp_wait.argtypes = [vp, i]
     lib.wrp_result.argtypes = [vp, i, i, C.POINTER(fp)]
+    if hasattr(lib, "wrp_result_frame"):
+        lib.wrp_result_frame.argtypes = [vp, i, i, i, i, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t)]
     lib.wrp_process_device.argtypes = [vp, vp, vp, vp]
     lib.wrp_process_batch_device.argtypes = [vp, vp, i, vp, vp]
     lib.wrp_process_host.argtypes = [vp, vp, i, vp]
@@ -218,6 +220,13 @@ class Engine:
         p = C.POINTER(C.c_float)()
         self._check(self.lib.wrp_result(self._h, sector, elevation, C.byref(p)), "wrp_result")
         return np.ctypeslib.as_array(p, shape=(self.gates, 2))
+
+    def result_frame(self, sector, elevation=0, which=0, with_elevation=True):
+        """The product (0 = Zdb, 1 = Zdr) of (sector, elevation) as the GPU framed it for the wire: a copy of the bytes."""
+        p, nbytes = C.POINTER(C.c_ubyte)(), C.c_size_t()
+        self._check(self.lib.wrp_result_frame(self._h, sector, elevation, which, int(with_elevation), C.byref(p), C.byref(nbytes)),
+                    "wrp_result_frame")
+        return np.ctypeslib.as_array(p, shape=(nbytes.value,)).copy()
 
     def dump_stage(self, slot, stage, channel=0):
         shape, dt = STAGE_SHAPES(self.m, self.n)[stage]

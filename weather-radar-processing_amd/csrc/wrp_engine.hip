@@ -32,6 +32,7 @@ struct Slot {
     float2 *d_iq = nullptr;   // device [C][m][n]
     float2 *d_mid = nullptr;  // device [2][m/2][n]
     float *d_out = nullptr;   // device [m/2][2]
+    unsigned *d_frames = nullptr;   // device [2][1 + m/2]: the two products framed for the wire (N2)
     unsigned char *h_raw = nullptr;   // pinned [m*n][12] wire bytes (allocated on first use)
     unsigned char *d_raw = nullptr;
     hipEvent_t done = nullptr;
@@ -94,6 +95,7 @@ struct wrp_engine {
     // slots + host result table [elev][sector][gate][2]
     std::vector<Slot> slots;
     float *h_result = nullptr; // pinned
+    unsigned *h_frames = nullptr;   // pinned [elev][sector][2][1 + m/2]: header word + big-endian floats, as the GPU wrote them
     // dump scratch
     void *d_dump = nullptr;
     size_t dump_bytes = 0;
@@ -221,10 +223,12 @@ void launch_doppler_t(wrp_engine *h, const float2 *d_mid, int n_sectors, float *
 }
 
 void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_out, hipStream_t st,
-                    const wrp::DumpPtrs *dump)
+                    const wrp::DumpPtrs *dump, unsigned *frames = nullptr, unsigned frame_hdr = 0)
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
+    none.frames = frames;        // (the dump launches never frame: wrp_dump_stage)
+    none.frame_hdr = frame_hdr;
     if (h->tuned_b && !(dump && (dump->hamm || dump->fft1))) {
         const wrp_config &c = h->cfg;
         const dim3 grid(c.m / 2 / (wrp::DB_WAVES * 2), n_sectors), block(wrp::DB_WAVES * 64);
@@ -296,7 +300,7 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
 }
 
 int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
-                 hipStream_t st, const wrp::DumpPtrs *dump);
+                 hipStream_t st, const wrp::DumpPtrs *dump, unsigned *frames = nullptr, unsigned frame_hdr = 0);
 size_t sector_elems(const wrp_config &c);
 
 // the two-kernel path over a whole batch, in chunks of max_batch sectors, on stream st (shared workspace d_mid: the
@@ -382,15 +386,25 @@ int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, h
 }
 
 int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
-                 hipStream_t st, const wrp::DumpPtrs *dump)
+                 hipStream_t st, const wrp::DumpPtrs *dump, unsigned *frames, unsigned frame_hdr)
 {
     launch_range(h, d_iq, n_sectors, d_mid, st, dump);
-    launch_doppler(h, d_mid, n_sectors, d_out, st, dump);
+    launch_doppler(h, d_mid, n_sectors, d_out, st, dump, frames, frame_hdr);
     HIP_TRY(h, hipGetLastError());
     return WRP_OK;
 }
 
 size_t sector_elems(const wrp_config &c) { return (size_t)c.channels * c.m * c.n; }
+// [sector BE16][elevation BE16] as one little-endian word of device / host memory
+unsigned frame_header_word(int sector, int elevation)
+{
+    return ((unsigned)(sector >> 8) & 0xffu) | (((unsigned)sector & 0xffu) << 8) | (((unsigned)(elevation >> 8) & 0xffu) << 16) |
+           (((unsigned)elevation & 0xffu) << 24);
+}
+unsigned *frames_of(wrp_engine *h, int sector, int elevation)
+{
+    return h->h_frames + ((size_t)elevation * h->cfg.n_sectors + sector) * 2 * (1 + h->cfg.m / 2);
+}
 size_t mid_elems(const wrp_config &c) { return (size_t)2 * (c.m / 2) * c.n; }
 
 int destroy_impl(wrp_engine *h)
@@ -408,6 +422,7 @@ int destroy_impl(wrp_engine *h)
         if (s.d_iq) (void)hipFree(s.d_iq);
         if (s.d_mid) (void)hipFree(s.d_mid);
         if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_frames) (void)hipFree(s.d_frames);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
@@ -422,6 +437,7 @@ int destroy_impl(wrp_engine *h)
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->d_dump) (void)hipFree(h->d_dump);
     if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->h_frames) (void)hipHostFree(h->h_frames);
     if (h->d_wr) (void)hipFree(h->d_wr);
     if (h->d_wd) (void)hipFree(h->d_wd);
     if (h->d_tw_m) (void)hipFree(h->d_tw_m);
@@ -525,6 +541,9 @@ int create_impl(wrp_engine *h)
     const size_t table = (size_t)c.n_elevations * c.n_sectors * (c.m / 2) * 2;
     HIP_TRY(h, hipHostMalloc(&h->h_result, sizeof(float) * table, hipHostMallocDefault));
     std::memset(h->h_result, 0, sizeof(float) * table);
+    const size_t ftable = (size_t)c.n_elevations * c.n_sectors * 2 * (1 + c.m / 2);
+    HIP_TRY(h, hipHostMalloc(&h->h_frames, sizeof(unsigned) * ftable, hipHostMallocDefault));
+    std::memset(h->h_frames, 0, sizeof(unsigned) * ftable);
 
     h->slots.resize(c.n_slots);
     for (auto &s : h->slots) {
@@ -534,6 +553,7 @@ int create_impl(wrp_engine *h)
         HIP_TRY(h, hipMalloc(&s.d_iq, sizeof(float2) * sector_elems(c)));
         HIP_TRY(h, hipMalloc(&s.d_mid, sizeof(float2) * mid_elems(c)));
         HIP_TRY(h, hipMalloc(&s.d_out, sizeof(float) * (c.m / 2) * 2));
+        HIP_TRY(h, hipMalloc(&s.d_frames, sizeof(unsigned) * 2 * (1 + c.m / 2)));
     }
     return WRP_OK;
 }
@@ -619,10 +639,11 @@ int wrp_submit(wrp_handle h, int slot, int sector, int elevation)
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(s.d_iq, s.h_iq, sizeof(float2) * sector_elems(c), hipMemcpyHostToDevice, s.stream));
-    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr);
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr, s.d_frames, frame_header_word(sector, elevation));
     if (rc != WRP_OK) return rc;
     float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
     HIP_TRY(h, hipMemcpyAsync(dst, s.d_out, sizeof(float) * (c.m / 2) * 2, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(frames_of(h, sector, elevation), s.d_frames, sizeof(unsigned) * 2 * (1 + c.m / 2), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(h, hipEventRecord(s.done, s.stream));
     s.busy = true;
     s.loaded = true;
@@ -657,10 +678,11 @@ int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation)
     HIP_TRY(h, hipMemcpyAsync(s.d_raw, s.h_raw, (size_t)count * 12, hipMemcpyHostToDevice, s.stream));
     hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256), dim3(256), 0, s.stream,
                        (const unsigned *)s.d_raw, s.d_iq, count, c.channels);
-    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr);
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr, s.d_frames, frame_header_word(sector, elevation));
     if (rc != WRP_OK) return rc;
     float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
     HIP_TRY(h, hipMemcpyAsync(dst, s.d_out, sizeof(float) * (c.m / 2) * 2, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(frames_of(h, sector, elevation), s.d_frames, sizeof(unsigned) * 2 * (1 + c.m / 2), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(h, hipEventRecord(s.done, s.stream));
     s.busy = true;
     s.loaded = true;
@@ -683,6 +705,23 @@ int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr)
         elevation >= h->cfg.n_elevations)
         return WRP_ERR_INVALID;
     *zdb_zdr = h->h_result + ((size_t)elevation * h->cfg.n_sectors + sector) * (h->cfg.m / 2) * 2;
+    return WRP_OK;
+}
+
+int wrp_result_frame(wrp_handle h, int sector, int elevation, int which, int with_elevation, const unsigned char **frame, size_t *bytes)
+{
+    if (!h || !frame || which < 0 || which > 1 || sector < 0 || sector >= h->cfg.n_sectors || elevation < 0 ||
+        elevation >= h->cfg.n_elevations)
+        return WRP_ERR_INVALID;
+    unsigned char *f = reinterpret_cast<unsigned char *>(frames_of(h, sector, elevation) + (size_t)which * (1 + h->cfg.m / 2));
+    // the GPU wrote [sector BE16][elevation BE16][BE floats]; the 2-byte header of the UDP products (read_single.cc:510-517)
+    // is the sector in front of the floats: two bytes rewritten in place, nothing copied
+    f[0] = (unsigned char)((sector >> 8) & 0xff);
+    f[1] = (unsigned char)(sector & 0xff);
+    f[2] = (unsigned char)(((with_elevation ? elevation : sector) >> 8) & 0xff);
+    f[3] = (unsigned char)((with_elevation ? elevation : sector) & 0xff);
+    *frame = with_elevation ? f : f + 2;
+    if (bytes) *bytes = sizeof(float) * (size_t)(h->cfg.m / 2) + (with_elevation ? 4 : 2);
     return WRP_OK;
 }
 

@@ -29,6 +29,10 @@ struct DumpPtrs {       // all optional (nullptr = skip); one sector, one channe
     float *pow;         // [m/2][n]
     float *rowsum;      // [m/2]
     int channel;        // which channel the dump refers to
+    // not a dump: the products of sector 0 of the launch framed for the wire -- two planes of 1 + m/2 words,
+    // [header][m/2 BIG-ENDIAN floats], Zdb then Zdr (rpv2.cu:631-661 does the swap on the CPU, aftoab); nullptr = none
+    unsigned *frames;
+    unsigned frame_hdr; // the header word as it lies in memory: sector BE16, elevation BE16
 };
 
 struct MaTaps { float g[9]; };
@@ -538,13 +542,26 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
 }
 
 // a9: reflectivity (rpv2.cu:199-213): z = (gate*k_rr)^2 * k_cal * S_hh in double, rounded once
-__device__ __forceinline__ void reflectivity_store(float *out2, int gate, float s_hh, float s_vv, float k_rr, float k_cal)
+__device__ __forceinline__ void reflectivity_store(float *out2, int gate, float s_hh, float s_vv, float k_rr, float k_cal,
+                                                   unsigned *frames = nullptr, int gates = 0)
 {
     const double rng = (double)gate * (double)k_rr;
     const float z = (float)(rng * rng * (double)k_cal * (double)s_hh);
     const float zdb = 10.f * log10f(z);
     const float zdr = 10.f * (log10f(s_hh) - log10f(s_vv));
     *reinterpret_cast<float2 *>(out2) = make_float2(zdb, zdr);
+    if (frames) {   // wire-ready: the same bits, big-endian, planar (read_single.cc:510-520, rpv2.cu:631-661)
+        frames[1 + gate] = __builtin_bswap32(__builtin_bit_cast(unsigned, zdb));
+        frames[1 + gates + 1 + gate] = __builtin_bswap32(__builtin_bit_cast(unsigned, zdr));
+    }
+}
+// the header words of the two frames (one thread of the launch)
+__device__ __forceinline__ void frame_headers(const DumpPtrs &dump, int gates, bool first_thread)
+{
+    if (dump.frames && first_thread) {
+        dump.frames[0] = dump.frame_hdr;
+        dump.frames[1 + gates] = dump.frame_hdr;
+    }
 }
 
 template <bool DUMP, int TAPS>
@@ -569,7 +586,8 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 #pragma unroll
     for (int ch = 0; ch < 2; ch++)
         S[ch] = doppler_row<DUMP, TAPS>(x[ch], lds[w], s_tw, taps, l, gate, DUMP && dump.channel == ch && sec == 0, dump);
-    if (l == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal);
+    if (l == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, sec == 0 ? dump.frames : nullptr, gates);
+    frame_headers(dump, gates, threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0);
 }
 
 // =============================================================================================

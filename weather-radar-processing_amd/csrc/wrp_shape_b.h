@@ -353,7 +353,8 @@ __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     __syncthreads();
     const float S = doppler_row_128<TAPS, DUMP>(x, lds[w * 4 + sub], s_tw, taps, i, gate, DUMP && dump.channel == ch && sec == 0, dump);
     const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
-    if (i == 0 && ch == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal);
+    if (i == 0 && ch == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal, sec == 0 ? dump.frames : nullptr, gates);
+    frame_headers(dump, gates, threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0);
 }
 
 } // namespace wrp

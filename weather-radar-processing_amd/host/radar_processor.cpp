@@ -143,15 +143,18 @@ void RadarProcessor::copy_result_to_host(int, int, int stream)
 
 void RadarProcessor::send_results(int sector, int elevation)
 {
-    const float *r = nullptr;
-    status_ = wrp_result(eng_, sector, elevation, &r);
-    if (status_ != WRP_OK || !sink_) return;
-    std::vector<unsigned char> frame(4 * (size_t)output_rows + 4);
+    // rpv2.cu:620-663 copies each product out of the result table, swaps every float to big-endian on the CPU (aftoab) and
+    // prepends the header.  Here the GPU has written both products wire-ready into the pinned frame table:
+    // the frame is handed to the sink where it lies.
+    if (!sink_) return;
     std::unique_lock<std::mutex> lk;
     if (turn_) lk = std::unique_lock<std::mutex>(turn_->sink_mu);
     for (int which = 0; which < 2; which++) {
-        const size_t n = frame_result(r, output_rows, sector, elevation, which, with_elevation_, frame.data());
-        sink_(which, sector, elevation, frame.data(), n);
+        const unsigned char *frame = nullptr;
+        size_t n = 0;
+        status_ = wrp_result_frame(eng_, sector, elevation, which, with_elevation_ ? 1 : 0, &frame, &n);
+        if (status_ != WRP_OK) return;
+        sink_(which, sector, elevation, frame, n);
     }
 }
 
