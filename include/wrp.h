@@ -157,6 +157,14 @@ int wrp_result_frame(wrp_handle h, int sector, int elevation, int which, int wit
  * stream: hipStream_t as void*, NULL = the engine's compute stream.  Asynchronous. */
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream);
 int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream);
+/* The same for a batch in the WIRE format: d_raw = [n_sectors][m*n samples][12 bytes], hhI hhQ vvI vvQ vhI
+ * vhQ as big-endian int16 (sector.cpp:52-62) -- what wrp_pinned_raw_slot takes, for a whole sweep that already lies in
+ * device memory.  m = 1024, n = 512, >= WRP_FUSED_MIN_SECTORS sectors: the tile workgroups of the persistent launch read
+ * the samples themselves (byte swap + conversion in registers, in place of the fp32 loads): 6 MiB of HBM reads per sector
+ * instead of 8 and no decode pass.  Otherwise the batch is decoded 8 sectors at a time and runs the two kernels.  Results
+ * are bit-identical to Sector::fromByteArray + the scatter of rpv2.cu:372-383 + wrp_process_batch_device. */
+int wrp_process_batch_raw_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *stream);
+
 /* Completion and ordering.  The batch is ordered on the stream it is given (NULL: the engine's own stream);
  * ONE fused launch is in flight per handle: a batch on another stream first waits, on the device, for the
  * previous one.  wrp_check waits for every batch submitted so far.

@@ -416,3 +416,57 @@ def test_products_framed_on_the_gpu_are_byte_exact(wrp, oracle, sectors):
         e.submit_raw(0, 2, 0)
         e.wait(0)
         assert e.result_frame(2, 0, 1, False).tobytes() == oracle.frame_result(e.result(2, 0), 2, 0, 1, False).tobytes()
+
+
+def _wire(sector, vh_fill=0):
+    """[2][m][n] complex (integer-valued) -> the sector's wire bytes (sector.cpp:52-62): 12 bytes per sample, big-endian int16."""
+    m, n = sector.shape[1:]
+    w = np.full((m * n, 6), vh_fill, dtype=">i2")
+    for c in range(2):
+        w[:, 2 * c] = sector[c].real.ravel()
+        w[:, 2 * c + 1] = sector[c].imag.ravel()
+    return np.frombuffer(w.tobytes(), np.uint8)
+
+
+def test_wire_format_batch_goes_straight_into_the_fused_launch(wrp, oracle, sectors):
+    """SURVEY 8f N1 as specified: a sweep in the wire format resident on the device -> wrp_process_batch_raw_device.  For
+    1024 x 512 and >= 8 sectors the tile workgroups of the persistent launch read the 12-byte samples themselves (byte swap
+    + conversion in registers; 6 MiB of HBM reads per sector instead of 8, no decode pass).  Integer -> float is exact, so
+    the results must be BIT-IDENTICAL to the CPU decode (oracle, pinned by the reference's compiled sector.cpp) followed by
+    the planar path -- also for batches that run the two kernels (< 8 sectors), with garbage in the VH samples, for int16
+    extremes, and for the 2048 x 128 shape (decoded on the GPU, then its own kernels)."""
+    import torch
+    rng = np.random.default_rng(5)
+    count = 19
+    planar = np.stack([sectors[k % 3] for k in range(count)])
+    planar[7, :, :4, :8] = np.array([-32768 + 32767j, 32767 - 32768j, -1 + 0j, 0 - 1j], np.complex64)[:, None]    # extremes
+    raw = np.stack([_wire(planar[k], vh_fill=int(rng.integers(-30000, 30000))) for k in range(count)])
+    hh, vv, vh = oracle.sector_from_bytes(raw[7], M, N)
+    assert np.array_equal(oracle.sector_to_planar(hh, vv, vh, M, N, copies=2)[0], planar[7])       # the helper == the reference decode
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out = torch.zeros(count, M // 2, 2, device="cuda")
+    with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
+        want = e2.process_host(planar)
+    with wrp.Engine(device=0, n_slots=1) as e:
+        e.process_batch_raw_device(d_raw.data_ptr(), count, d_out.data_ptr())
+        e.check()
+        assert e.fused_fallbacks == 0 and e.lib.wrp_last_hip_error(e.handle) == b""
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        d_out.zero_()
+        e.process_batch_raw_device(d_raw.data_ptr(), 5, d_out.data_ptr())           # the two kernels behind decode_wire
+        e.check()
+        assert np.array_equal(d_out[:5].cpu().numpy().view(np.uint32), want[:5].view(np.uint32))
+    with wrp.Engine(device=0, n_slots=1, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:      # a launch that gives up is repeated from the raw bytes
+        d_out.zero_()
+        e.process_batch_raw_device(d_raw.data_ptr(), count, d_out.data_ptr())
+        e.check()
+        assert e.fused_fallbacks == 1
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    m, n = 2048, 128
+    pb = np.stack([oracle.synthetic_sector(s, m, n) for s in range(9)])
+    d_rb = torch.from_numpy(np.stack([_wire(x, 77) for x in pb])).cuda()
+    d_ob = torch.zeros(9, m // 2, 2, device="cuda")
+    with wrp.Engine(device=0, m=m, n=n, n_slots=1) as e:
+        e.process_batch_raw_device(d_rb.data_ptr(), 9, d_ob.data_ptr())
+        e.check()
+        assert np.array_equal(d_ob.cpu().numpy().view(np.uint32), e.process_host(pb).view(np.uint32))

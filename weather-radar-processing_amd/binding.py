@@ -121,6 +121,8 @@ def load_library():
     lib.wrp_process_device.argtypes = [vp, vp, vp, vp]
     lib.wrp_process_batch_device.argtypes = [vp, vp, i, vp, vp]
     lib.wrp_process_host.argtypes = [vp, vp, i, vp]
+    if hasattr(lib, "wrp_process_batch_raw_device"):
+        lib.wrp_process_batch_raw_device.argtypes = [vp, vp, i, vp, vp]
     lib.wrp_check.argtypes = [vp]
     if hasattr(lib, "wrp_fused_fallbacks"):      # absent from older builds that tools/ab.py may load beside this one
         lib.wrp_fused_fallbacks.argtypes = [vp]
@@ -251,6 +253,11 @@ class Engine:
         self._check(self.lib.wrp_process_batch_device(self._h, C.c_void_p(d_iq_ptr), n_sectors,
                                                       C.c_void_p(d_out_ptr), C.c_void_p(stream or 0)),
                     "wrp_process_batch_device")
+
+    def process_batch_raw_device(self, d_raw_ptr, n_sectors, d_out_ptr, stream=None):
+        """Wire-format batch [n_sectors][m*n][12 bytes] resident on the device (N1)."""
+        self._check(self.lib.wrp_process_batch_raw_device(self._h, C.c_void_p(d_raw_ptr), n_sectors, C.c_void_p(d_out_ptr),
+                                                          C.c_void_p(stream or 0)), "wrp_process_batch_raw_device")
 
     def check(self):
         """Wait for every batch submitted so far (a fused launch that gave up is repeated on the two-kernel path here)."""

@@ -42,6 +42,7 @@ struct Slot {
 
 constexpr int WRP_RING = 64;            // fused batches that may be outstanding (status words, events)
 constexpr int WRP_FUSED_COOLDOWN = 16;  // batches on the two-kernel path after a fused launch that gave up
+constexpr int WRP_RAW_CHUNK = 8;        // sectors decoded at a time when a wire-format batch runs the two kernels
 
 struct FusedLane {
     wrp::FusedCtl *d_ctl = nullptr;
@@ -50,7 +51,7 @@ struct FusedLane {
     bool used = false;
     bool ctl_dirty = true;              // memset before the next launch (first launch, after a failure)
 };
-struct FusedBatch { const float2 *in; int n; float *out; int slot; };
+struct FusedBatch { const float2 *in; int n; float *out; int slot; bool raw; };   // raw: `in` is the wire format
 
 } // namespace
 
@@ -92,6 +93,7 @@ struct wrp_engine {
     bool batch_pending = false;
     float2 *d_mid = nullptr;  // [max_batch][2][m/2][n]
     int max_batch = 0;
+    float2 *d_decode = nullptr;   // [WRP_RAW_CHUNK][C][m][n]: wire-format batches that do not take the fused launch (allocated on first use)
     // slots + host result table [elev][sector][gate][2]
     std::vector<Slot> slots;
     float *h_result = nullptr; // pinned
@@ -264,7 +266,7 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
 
 // one persistent launch for the whole batch: XCD teams keep the intermediate in their L2 (wrp_fused.h)
 int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_sectors, float *d_out, hipStream_t st, int slot,
-                 unsigned long long *d_stamps = nullptr)
+                 unsigned long long *d_stamps = nullptr, bool raw = false)
 {
     const wrp_config &c = h->cfg;
     // a successful launch leaves the control block zeroed (fused_leave): no memset node in front of the next one
@@ -282,6 +284,16 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
                        c.k_range_resolution, c.k_calibration, h->d_status + slot)
         if (h->taps_pad == 7) WRP_FUSED_B(7); else WRP_FUSED_B(9);
 #undef WRP_FUSED_B
+        HIP_TRY(h, hipGetLastError());
+        return WRP_OK;
+    }
+    if (raw) {   // the wire format straight into the tile workgroups (m = 1024, n = 512 only: the caller has checked)
+#define WRP_FUSED_RAW(TAPS)                                                                                           \
+    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, false, true>), dim3(grid), dim3(wrp::FUSED_THREADS),          \
+                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, nullptr)
+        if (h->taps_pad == 7) WRP_FUSED_RAW(7); else WRP_FUSED_RAW(9);
+#undef WRP_FUSED_RAW
         HIP_TRY(h, hipGetLastError());
         return WRP_OK;
     }
@@ -319,6 +331,25 @@ int launch_two_kernel_batch(wrp_engine *h, const float2 *in, int n_sectors, floa
     return WRP_OK;
 }
 
+// a wire-format batch on the two-kernel path: WRP_RAW_CHUNK sectors at a time are decoded (decode_wire) and transformed
+int launch_two_kernel_raw_batch(wrp_engine *h, const unsigned char *raw, int n_sectors, float *d_out, hipStream_t st)
+{
+    const wrp_config &c = h->cfg;
+    const int count = c.m * c.n;
+    if (!h->d_decode) HIP_TRY(h, hipMalloc(&h->d_decode, sizeof(float2) * sector_elems(c) * WRP_RAW_CHUNK));
+    if (h->batch_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_batch, 0));   // d_decode and d_mid are shared workspaces
+    for (int s0 = 0; s0 < n_sectors; s0 += WRP_RAW_CHUNK) {
+        const int cnt = std::min(WRP_RAW_CHUNK, n_sectors - s0);
+        hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256, cnt), dim3(256), 0, st,
+                           (const unsigned *)(raw + (size_t)s0 * count * 12), h->d_decode, count, c.channels);
+        const int rc = launch_chain(h, h->d_decode, cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
+        if (rc != WRP_OK) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_batch, st));
+    h->batch_pending = true;
+    return WRP_OK;
+}
+
 // A fused launch that gave up (bounded wait, or the CUs did not host 32 tile + 32 row workgroups per XCD: another kernel
 // on the GPU) has said so in its own pinned status word.  Its output is void: the batch is computed again, here and
 // synchronously, by the two kernels; the handle stays on them for WRP_FUSED_COOLDOWN batches and then tries again.
@@ -331,7 +362,8 @@ int redo_batch(wrp_engine *h, const FusedBatch &b, unsigned status)
     const std::string note = (status & 2)
         ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; batch repeated on the two-kernel path"
         : "fused launch: a bounded wait gave up (workgroups not co-resident?); batch repeated on the two-kernel path";
-    int rc = launch_two_kernel_batch(h, b.in, b.n, b.out, h->stream);
+    int rc = b.raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)b.in, b.n, b.out, h->stream)
+                   : launch_two_kernel_batch(h, b.in, b.n, b.out, h->stream);
     if (rc != WRP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->batch_pending = false;
@@ -364,24 +396,26 @@ int reap_fused(wrp_engine *h, bool block, size_t leave = 0)
 }
 
 // fused launch of one batch; stream = the caller's or nullptr (the engine's)
-int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream)
+int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream, bool raw = false)
 {
     if (h->outstanding.size() >= (size_t)WRP_RING) {
         const int rc = reap_fused(h, true, WRP_RING - 1);
         if (rc != WRP_OK) return rc;
-        if (!h->fused_armed) return launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? stream : h->stream);
+        if (!h->fused_armed)
+            return raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, stream ? stream : h->stream)
+                       : launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? stream : h->stream);
     }
     FusedLane &lane = h->lane;
     hipStream_t st = stream ? stream : h->stream;
     if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // control block and slots are free again (free on one stream)
     const int slot = h->ring_next;
     h->ring_next = (h->ring_next + 1) % WRP_RING;
-    const int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot);
+    const int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot, nullptr, raw);
     if (rc != WRP_OK) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_ring[slot], st));
     HIP_TRY(h, hipEventRecord(lane.done, st));
     lane.used = true;
-    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot});
+    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, raw});
     return WRP_OK;
 }
 
@@ -430,6 +464,7 @@ int destroy_impl(wrp_engine *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->d_mid) (void)hipFree(h->d_mid);
+    if (h->d_decode) (void)hipFree(h->d_decode);
     if (h->lane.done) (void)hipEventDestroy(h->lane.done);
     if (h->lane.d_ctl) (void)hipFree(h->lane.d_ctl);
     if (h->lane.d_pool) (void)hipFree(h->lane.d_pool);
@@ -485,6 +520,10 @@ int create_impl(wrp_engine *h)
     WRP_FUSED_ATTR(7, false); WRP_FUSED_ATTR(9, false);
     WRP_FUSED_ATTR(7, true);  WRP_FUSED_ATTR(9, true);
 #undef WRP_FUSED_ATTR
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<7, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<9, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES));
     HIP_TRY(h, hipEventCreateWithFlags(&h->lane.done, hipEventDisableTiming));
     HIP_TRY(h, hipMalloc(&h->lane.d_ctl, sizeof(wrp::FusedCtl)));
     HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
@@ -738,6 +777,21 @@ int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, floa
     rc = launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? (hipStream_t)stream : h->stream);
     if (rc == WRP_OK && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
         h->fused_armed = true;     // the fused launch gets another chance
+    return rc;
+}
+
+int wrp_process_batch_raw_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *stream)
+{
+    if (!h || !d_raw || !d_out || n_sectors < 0) return WRP_ERR_INVALID;
+    if (n_sectors == 0) return WRP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = reap_fused(h, false);
+    if (rc != WRP_OK) return rc;
+    if (h->tuned && h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS)
+        return submit_fused(h, (const float2 *)d_raw, n_sectors, d_out, (hipStream_t)stream, true);
+    rc = launch_two_kernel_raw_batch(h, (const unsigned char *)d_raw, n_sectors, d_out, stream ? (hipStream_t)stream : h->stream);
+    if (rc == WRP_OK && h->tuned && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
+        h->fused_armed = true;
     return rc;
 }
 

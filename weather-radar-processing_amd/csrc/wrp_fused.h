@@ -55,6 +55,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wrp_kernels.h"
 
 namespace wrp {
@@ -296,6 +298,14 @@ __device__ __forceinline__ void fused_stage1_tables(const unsigned char *smem, F
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++) t.tw[k1] = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
 }
+// one wire sample of one channel, I and Q as big-endian int16 in a dword (sector.cpp:52-62) -> the two floats the CPU
+// decode + scatter puts into the planar block (rpv2.cu:372-383); exact, so everything behind it is bit-identical.
+// v[r] of the wire-format launch holds the RAW dwords (hh, vv) of the lane's two samples of row r: x, y first sample, z, w second.
+__device__ __forceinline__ cf wire_sample(float bits)
+{
+    const unsigned t = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, bits), __builtin_bit_cast(unsigned, bits), 0x02030001u);   // swap the bytes of both halves
+    return make_float2((float)(short)(t & 0xffffu), (float)(short)(t >> 16));
+}
 template <int COLUMN>   // 0: the lane's first column (v[r].xy), 1: its second (v[r].zw)
 __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const FusedStage1Tables &t, cf (&g)[8])
 {
@@ -355,27 +365,21 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;   // position w*64 of this lane's column
-    // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place; two items per lane, p1 = (l >> 4) + 4 it.
-    // The reads of BOTH items and the first item's twiddles go out in one batch; the second item's twiddles are read
-    // while the first item is transformed: two LDS round trips stand in the open instead of four.
-    const int pa = l >> 4, pb = pa + 4;
-    cf a[8], b[8], t[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + pa * T::ROW_BYTES);
+    for (int it = 0; it < 2; it++) {   // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
+        const int p1 = (l >> 4) + 4 * it;
+        cf a[8], t[8];   // the seven twiddles in one batch with the data, not one LDS round trip each
 #pragma unroll
-    for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(pa, k2));
+        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
 #pragma unroll
-    for (int r = 0; r < 8; r++) b[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + pb * T::ROW_BYTES);
-    fft8<-1>(a);
-    *reinterpret_cast<float2 *>(base + pa * T::ROW_BYTES) = a[0];
+        for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
+        fft8<-1>(a);
+        *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
 #pragma unroll
-    for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + pa * T::ROW_BYTES) = cmul(a[k2], t[k2]);
-#pragma unroll
-    for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(pb, k2));
-    fft8<-1>(b);
-    *reinterpret_cast<float2 *>(base + pb * T::ROW_BYTES) = b[0];
-#pragma unroll
-    for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + pb * T::ROW_BYTES) = cmul(b[k2], t[k2]);
+        for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t[k2]);
+    }
+    // (both items' reads in one batch, the second item's twiddles read under the first item's butterfly -- two LDS round
+    // trips in the open instead of four, 128 registers -- measured the same in the launch: profiles/r03/ab_stage23_interleaved.log)
     wave_lds_fence();
 }
 __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
@@ -386,19 +390,16 @@ __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
-    // stage 3: radix 8 over the 8 contiguous positions k2*8 + r, k2 = (l >> 4) + 4 it; both items read in one batch
-    const int ka = l >> 4, kb = ka + 4;
-    cf a[8], b[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + ka * T::BLK_BYTES + r * T::ROW_BYTES);
+    for (int it = 0; it < 2; it++) {   // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
+        const int k2 = (l >> 4) + 4 * it;
+        cf a[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) b[r] = *reinterpret_cast<const float2 *>(base + kb * T::BLK_BYTES + r * T::ROW_BYTES);
-    fft8<-1>(a);
+        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
+        fft8<-1>(a);
 #pragma unroll
-    for (int k3 = 0; k3 < 4; k3++) o[0][k3] = a[k3];
-    fft8<-1>(b);
-#pragma unroll
-    for (int k3 = 0; k3 < 4; k3++) o[1][k3] = b[k3];
+        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
+    }
 }
 __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
 {
@@ -517,9 +518,147 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
     if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; }
 }
 
-template <int TAPS, bool STAMPS>
+// stage 1 of the wire-format launch: as fused_stage1<COLUMN, CH>, but the twiddles are read HERE, behind the butterfly, in
+// two batches of eight (group 0, then group 1).  During the HH task the registers still hold the sector's VV dwords (16 to
+// 32 more live registers than the planar launch has at this point): fifteen twiddles held across both columns, as there,
+// cost 40 spilled registers.  Same arithmetic, same order.
+template <int COLUMN, int CH>
+__device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&g)[8])
+{
+    typedef FusedTile T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, cp = l & 7;
+    const int p0 = w * 8 + (l >> 3);
+    const int slot = T::addr(p0, cp) + 8 * COLUMN;
+    const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
+    const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);
+    cf a[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float wgt = s_wr[p0 + 64 * r] * (COLUMN ? wdv.y : wdv.x);
+        const cf x = wire_sample(COLUMN ? (CH ? v[r].w : v[r].z) : (CH ? v[r].y : v[r].x));
+        a[r] = make_float2(x.x * wgt, x.y * wgt);
+    }
+    fft16<-1>(a);
+    *reinterpret_cast<float2 *>(smem + slot) = a[0];
+    cf t[8];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) t[k1] = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t[k1]);
+#pragma unroll
+    for (int k1 = 8; k1 < 16; k1++) t[k1 - 8] = *reinterpret_cast<const float2 *>(tw1 + T::tw1_addr(0, k1) - T::tw1_addr(0, 0));
+#pragma unroll
+    for (int k1 = 8; k1 < 16; k1++) g[k1 - 8] = cmul(a[k1], t[k1 - 8]);
+}
+
+// ---- wire-format input: the tile workgroups read the sector as it arrives -------------------------------
+// 12 bytes per sample: hhI hhQ vvI vvQ vhI vhQ, big-endian int16 (sector.cpp:52-62), [1024 rows][512 samples].  A lane
+// takes the (hh, vv) dwords of its two samples of a row with two 8-byte loads; ONE set of 64 registers then feeds BOTH
+// channel-tasks of the sector (the planar form needs one per task), VH is never fetched into a register, and the byte
+// swap + conversion happen in stage 1 in place of nothing (three instructions per sample and channel).  HBM: 6 MiB per
+// sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
+template <int QUARTER>
+__device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
+                                                    float4 (&v)[16], float2 &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int p0 = w * 8 + (l >> 3), cp = l & 7;
+    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * 12u : 0u);
+    const int voff = (p0 * DP_N + col_base + cp * 2) * 12;
+#pragma unroll
+    for (int r = QUARTER; r < 16; r += 4) {
+        const float2 a = buf_load_f2<AUX_NT>(rs, voff, 64 * r * DP_N * 12);
+        const float2 b = buf_load_f2<AUX_NT>(rs, voff + 12, 64 * r * DP_N * 12);
+        v[r] = make_float4(a.x, a.y, b.x, b.y);
+    }
+    if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
+}
+
+// The tile member of the wire-format launch: the loop of fused_chain_1024x512's tile member with the two channel-tasks of
+// a sector unrolled -- task HH (no requests: the registers still hold the sector's VV dwords) and task VV (behind its stage
+// 1 the next sector's tile is requested in quarters, eight loads each).  Same hand-over protocol, same sequence numbers.
+__device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const unsigned *raw, float2 *mid, FusedCtl *ctl,
+                                                      const RangeConsts &rc, int xcc, int rank, int teams, int trank, int tasks)
+{
+    typedef FusedTile T;
+    const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
+    // the tile of a sector (both its tasks): rotated from sector to sector as in the planar launch
+    auto tile_col = [&](int sec) { return ((rank + sec) & (FUSED_MEMBERS - 1)) * 16; };
+    auto sector_src = [&](int sec) { return raw + (size_t)(trank + sec * teams) * RP_M * DP_N * 3; };
+    const int sectors = tasks >> 1;
+    float4 v[16];
+    float2 wdv;
+    fused_raw_tile_load<0>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<1>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<2>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<3>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    for (int e = tid; e < RP_M; e += FUSED_THREADS) {
+        const int p0 = e >> 4, k1 = e & 15;
+        *reinterpret_cast<float2 *>(smem + T::tw1_addr(p0, k1)) = rc.tw[(p0 * k1) & (RP_M - 1)];
+        reinterpret_cast<float *>(smem + T::OFF_WR)[e] = rc.wr_c[e];
+    }
+    if (tid < 64) *reinterpret_cast<float2 *>(smem + T::tw2_addr(tid >> 3, tid & 7)) = rc.tw[(16 * (tid >> 3) * (tid & 7)) & (RP_M - 1)];
+    __syncthreads();
+    int *s_arrived = reinterpret_cast<int *>(smem + T::OFF_CTL + 56);
+    if (tid < 2) s_arrived[tid] = 0;
+    __syncthreads();
+    const FusedFlags *my_loaded0 = &ctl->loaded[0][xcc][rank], *my_loaded1 = &ctl->loaded[1][xcc][rank];
+    int failed = 0;
+    // one channel-task; CH = 1 also requests the next sector's tile (valid = false behind the last sector)
+    auto task = [&](auto chc, int q, int col, const unsigned *next, int next_col, bool more) {
+        constexpr int CH = decltype(chc)::value;
+        cf ga[8], gc[8];
+        fused_stage1_raw<0, CH>(smem, v, wdv, ga);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // half 1 of the previous task: drained, counted by the last wave
+        int last = 0;
+        if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
+        if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
+        fused_stage1_raw<1, CH>(smem, v, wdv, gc);
+        __syncthreads();                    // A1
+        cf o[2][4];
+        if (CH) fused_raw_tile_load<0>(next, next_col, rc.wd, v, wdv, more);
+        fused_stage2(smem);
+        if (CH) fused_raw_tile_load<1>(next, next_col, rc.wd, v, wdv, more);
+        fused_stage3(smem, o);
+        spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
+        __syncthreads();                    // A2
+        fused_store(mid, col, 0, o);
+        __builtin_amdgcn_sched_barrier(0);
+        if (CH) fused_raw_tile_load<2>(next, next_col, rc.wd, v, wdv, more);
+        fused_group1_to_lds(smem, ga, gc);
+        if (CH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 requests just issued: the stores are in the L2
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = 0;
+        if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
+        if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
+        __syncthreads();                    // A3
+        if (CH) fused_raw_tile_load<3>(next, next_col, rc.wd, v, wdv, more);
+        fused_stage2(smem);
+        fused_stage3(smem, o);
+        spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
+        __syncthreads();                    // A4
+        fused_store(mid, col, 1, o);
+    };
+#pragma unroll 1
+    for (int sec = 0; sec < sectors; sec++) {
+        const bool more = sec + 1 < sectors;
+        task(std::integral_constant<int, 0>{}, 2 * sec, tile_col(sec), nullptr, 0, false);
+        task(std::integral_constant<int, 1>{}, 2 * sec + 1, tile_col(sec), sector_src(more ? sec + 1 : 0), tile_col(sec + 1), more);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tasks > 0 && w == 0) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)tasks);
+    if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int TAPS, bool STAMPS, bool RAW = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_1024x512(
-    const float2 *__restrict__ iq,   // [S][C][1024][512]
+    const float2 *__restrict__ iq,   // [S][C][1024][512]; RAW: the wire format, [S][1024 x 512][12 bytes]
     float *__restrict__ out,         // [S][512][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
@@ -562,7 +701,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         }
     };
 
-    if (kind == 0) {
+    if (RAW && kind == 0) {
+        fused_raw_tile_member(smem, reinterpret_cast<const unsigned *>(iq), mid, ctl, rc, xcc, rank, teams, trank, tasks);
+        fused_leave(ctl, host_status, xcc, s_ctl);
+    } else if (kind == 0) {
         // =============================== tile member ===============================
         // Tile of task q: (rank + q) mod 32.  The column tiles 3, 11, 19, 27 -- byte offset 384 mod 1024 of
         // every 4 KiB row -- load 18 % slower than the others on this chip (tools/storeskew.hip; an

@@ -597,12 +597,14 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 // `channels` coalesced 8-byte stores.  Integer -> float is exact, so this is bit-identical to
 // Sector::fromByteArray + the scatter loop.
 // =============================================================================================
-__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [count][3] dwords
-                                                    float2 *__restrict__ iq,            // [channels][count]
+__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [sectors = gridDim.y][count][3] dwords
+                                                    float2 *__restrict__ iq,            // [sectors][channels][count]
                                                     int count, int channels)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
+    raw += (size_t)blockIdx.y * count * 3;
+    iq += (size_t)blockIdx.y * channels * count;
     const unsigned w0 = raw[3 * t], w1 = raw[3 * t + 1], w2 = raw[3 * t + 2];
     const unsigned w[3] = {__builtin_bswap32(w0), __builtin_bswap32(w1), __builtin_bswap32(w2)};
 #pragma unroll
