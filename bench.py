@@ -314,6 +314,39 @@ def main():
               "samples": 200, "what": "median wall time of one wrp_submit -> wrp_wait from a pinned slot (PCIe included) and of one "
                                       "wrp_process_batch_device(1 sector) -> wrp_check on device-resident input; two-kernel path"}
 
+    # The same sweep in the WIRE format, device-resident: the tile workgroups of the fused launch read the
+    # 12-byte samples themselves.  A roofline entry of its own -- the headline stays on the fp32 definition of SURVEY 8d.
+    wire = None
+    if args.shape == "A":
+        wsec = []
+        for k in range(8):
+            w = np.zeros((m * n, 6), dtype=">i2")
+            for c in range(2):
+                w[:, 2 * c] = pool[k][c].real.ravel()
+                w[:, 2 * c + 1] = pool[k][c].imag.ravel()
+            wsec.append(np.frombuffer(w.tobytes(), np.uint8))
+        d_wpool = torch.from_numpy(np.stack(wsec)).to(dev)
+        d_raw = d_wpool[torch.arange(S, device=dev) % 8].contiguous()          # [S][m*n*12] bytes: 2.2 GiB, distinct blocks
+        d_out_w = torch.empty_like(d_out)
+        del d_wpool
+        for _ in range(max(args.warmup, 10)):
+            eng.process_batch_raw_device(d_raw.data_ptr(), S, d_out_w.data_ptr())
+        eng.check()
+        wsteps = max(10, min(args.steps, 100))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(wsteps):
+            eng.process_batch_raw_device(d_raw.data_ptr(), S, d_out_w.data_ptr())
+        eng.check()
+        barrier()
+        wdt = max_over_ranks(time.perf_counter() - t0)
+        walgo = m * n * 12 + (m // 2) * 8
+        wire = {"value": round(world * S * wsteps / wdt, 1), "unit": "sectors/s", "steps": wsteps,
+                "algorithmic_bytes_per_sector": walgo, "achieved": round(walgo * S * wsteps / wdt / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "frac": round(walgo * S * wsteps / wdt / 1e9 / HBM_PEAK_GBS, 4), "bit_identical_to_planar": bool(torch.equal(d_out_w, d_out)),
+                "what": "wrp_process_batch_raw_device: 12 B/sample big-endian int16 read by the tile workgroups (6 MiB/sector), wall clock"}
+        del d_raw, d_out_w
+
     # end to end: every sector crosses PCIe.  Wire-format sector (12 B/sample, big-endian int16, 6 MiB) in
     # the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB, 4 slots cascading, all ranks at once.
     end_to_end = None
@@ -387,6 +420,8 @@ def main():
         "single_sector": single,
         "roofline": roofline,
     }
+    if wire is not None:
+        line["wire_format_input"] = wire
     if end_to_end is not None:
         line["end_to_end"] = end_to_end
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

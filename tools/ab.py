@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shape", choices=["A", "B"], default="A")
     ap.add_argument("--no-check", action="store_true", help="timing-only builds whose results are wrong on purpose")
+    ap.add_argument("--wire", action="store_true", help="time wrp_process_batch_raw_device (wire-format input) instead")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,6 +55,28 @@ def main():
         ok = bool(np.max(np.abs(d_out[1].cpu().numpy()[1:] - want[1:])) < 1e-3)
         engines.append((os.path.basename(path), e, ok, []))
     k = 1e3 / (args.iters * S)
+    if args.wire:
+        import time
+        w = np.zeros((4, m * n, 6), dtype=">i2")
+        for q in range(4):
+            for c in range(2):
+                w[q, :, 2 * c] = pool[q][c].real.ravel()
+                w[q, :, 2 * c + 1] = pool[q][c].imag.ravel()
+        d_w = torch.from_numpy(np.frombuffer(w.tobytes(), np.uint8).reshape(4, -1)).to(dev)
+        d_raw = d_w[torch.arange(S, device=dev) % 4].contiguous()
+
+        class Timed:
+            def __init__(self, e):
+                self.e = e
+
+            def time_batch_device(self, a, S_, o, iters, per_kernel=False):
+                self.e.check()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self.e.process_batch_raw_device(d_raw.data_ptr(), S_, o)
+                self.e.check()
+                return ((time.perf_counter() - t0) * 1e3, None, None)
+        engines = [(nm, Timed(e), ok, tt) for nm, e, ok, tt in engines]
     for _ in range(5):                                    # settle
         for _, e, _, _ in engines:
             e.time_batch_device(d_iq.data_ptr(), S, d_out.data_ptr(), args.iters, per_kernel=False)

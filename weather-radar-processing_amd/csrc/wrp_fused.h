@@ -560,6 +560,13 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
 // channel-tasks of the sector (the planar form needs one per task), VH is never fetched into a register, and the byte
 // swap + conversion happen in stage 1 in place of nothing (three instructions per sample and channel).  HBM: 6 MiB per
 // sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
+// Cache policy of the wire-format loads.  A lane's two 8-byte loads of a row touch the same one or two 128-byte lines, and
+// so do its neighbours': with plain loads the second touch is served by the CU's L1; non-temporal (as the planar launch's
+// input) every touch goes to the L2 -- 3.30 against 2.96 us/sector (profiles/r03/ab_wire_input_policy.log).
+#ifndef WRP_FUSED_RAW_AUX
+#define WRP_FUSED_RAW_AUX 0
+#endif
+constexpr int FUSED_RAW_AUX = WRP_FUSED_RAW_AUX;
 template <int QUARTER>
 __device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
                                                     float4 (&v)[16], float2 &wdv, bool valid)
@@ -572,8 +579,8 @@ __device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /
     const int voff = (p0 * DP_N + col_base + cp * 2) * 12;
 #pragma unroll
     for (int r = QUARTER; r < 16; r += 4) {
-        const float2 a = buf_load_f2<AUX_NT>(rs, voff, 64 * r * DP_N * 12);
-        const float2 b = buf_load_f2<AUX_NT>(rs, voff + 12, 64 * r * DP_N * 12);
+        const float2 a = buf_load_f2<FUSED_RAW_AUX>(rs, voff, 64 * r * DP_N * 12);
+        const float2 b = buf_load_f2<FUSED_RAW_AUX>(rs, voff + 12, 64 * r * DP_N * 12);
         v[r] = make_float4(a.x, a.y, b.x, b.y);
     }
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
