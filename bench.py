@@ -156,6 +156,7 @@ def main():
                     help="seconds of untimed launches before the warm-up steps (profiling passes shorten it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-sector latency and wire-format sections (profiling passes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -262,10 +263,11 @@ def main():
     achieved = algo / t_sector / 1e9
     c2 = wrp_amd.WrpConfig()
     eng.lib.wrp_get_config(eng.handle, c2)
-    fused = args.shape == "A" and (c2.flags & wrp_amd.FLAG_TWO_KERNELS) == 0 and S >= wrp_amd.FUSED_MIN_SECTORS
+    fused = (c2.flags & (wrp_amd.FLAG_TWO_KERNELS | wrp_amd.FLAG_GENERIC_KERNELS)) == 0 and S >= wrp_amd.FUSED_MIN_SECTORS
     per_launch = S if fused else min(S, c2.max_batch)
     launches = 1 if fused else -(-S // c2.max_batch)
-    kernel = ("fused_chain_1024x512 (one persistent launch per sweep: tile + row workgroups, intermediate in the XCDs' L2)"
+    kernel = (("fused_chain_1024x512" if args.shape == "A" else "fused_chain_2048x128") +
+              " (one persistent launch per sweep: tile + row workgroups, intermediate in the XCDs' L2)"
               if fused else "range_pass_1024_persistent + doppler_pass_512 (one launch pair per chunk)" if args.shape == "A"
               else "range_pass_2048 + doppler_pass_128 (one launch pair per chunk)")
     # HBM traffic per launch from the rocprofv3 PMC run of the SAME library sources (FETCH_SIZE / WRITE_SIZE in
@@ -300,24 +302,24 @@ def main():
     import statistics
     eng.slot_array(0)[:] = pool[0]
     lat, lat_dev = [], []
-    for k in range(210):
+    for k in range(0 if args.no_extras else 210):
         t0 = time.perf_counter()
         eng.submit(0, 0, 0)
         eng.wait(0)
         lat.append((time.perf_counter() - t0) * 1e6)
-    for k in range(210):
+    for k in range(0 if args.no_extras else 210):
         t0 = time.perf_counter()
         eng.process_batch_device(d_iq.data_ptr(), 1, d_out.data_ptr())
         eng.check()
         lat_dev.append((time.perf_counter() - t0) * 1e6)
-    single = {"submit_wait_pinned_us": round(statistics.median(lat[10:]), 1), "device_resident_us": round(statistics.median(lat_dev[10:]), 1),
+    single = None if args.no_extras else {"submit_wait_pinned_us": round(statistics.median(lat[10:]), 1), "device_resident_us": round(statistics.median(lat_dev[10:]), 1),
               "samples": 200, "what": "median wall time of one wrp_submit -> wrp_wait from a pinned slot (PCIe included) and of one "
                                       "wrp_process_batch_device(1 sector) -> wrp_check on device-resident input; two-kernel path"}
 
     # The same sweep in the WIRE format, device-resident: the tile workgroups of the fused launch read the
     # 12-byte samples themselves.  A roofline entry of its own -- the headline stays on the fp32 definition of SURVEY 8d.
     wire = None
-    if args.shape == "A":
+    if args.shape == "A" and (not args.no_extras or os.environ.get("WRP_BENCH_WIRE")):
         wsec = []
         for k in range(8):
             w = np.zeros((m * n, 6), dtype=">i2")
@@ -416,7 +418,7 @@ def main():
                    "launch": "fused" if fused else "two kernels", "untimed_settle_s": args.settle},
         "achieved_hbm_GBps": round(world * achieved, 1),
         "spot_check_vs_oracle": ok,
-        "single_sector_latency_us": single["submit_wait_pinned_us"],
+        "single_sector_latency_us": single["submit_wait_pinned_us"] if single else None,
         "single_sector": single,
         "roofline": roofline,
     }

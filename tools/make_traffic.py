@@ -39,6 +39,8 @@ def main():
         v["bytes_corrected"] = (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024
         out[k] = v
     chain = [k for k in out if k.startswith(("fused_chain", "range_pass", "doppler_pass"))]
+    if len(sys.argv) > 3:      # the kernel(s) of the chain named explicitly (a run that launched other forms as well)
+        chain = [k for k in chain if sys.argv[3] in k]
     out["chain"] = chain
     out["fused"] = any(k.startswith("fused_chain") for k in chain)
     out["bytes_per_launch"] = sum(out[k]["bytes_corrected"] for k in chain)

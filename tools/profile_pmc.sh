@@ -5,7 +5,7 @@
 # usage: tools/profile_pmc.sh <outdir> [bench args...]
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:---steps 3 --warmup 2 --settle 0.01 --sectors 360 --no-cpu-baseline --no-end-to-end}
+ARGS=${@:---steps 3 --warmup 2 --settle 0.01 --sectors 360 --no-cpu-baseline --no-end-to-end --no-extras}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p "$OUT"
 pass() {

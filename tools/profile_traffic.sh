@@ -2,7 +2,7 @@
 # FETCH_SIZE / WRITE_SIZE passes only (rocprofv3 --pmc, separate passes) around bench.py; usage as profile_pmc.sh
 set -u
 OUT=${1:-gpurun_out/pmc_t}; shift || true
-ARGS=${@:---steps 3 --warmup 2 --settle 0.01 --sectors 360 --no-cpu-baseline --no-end-to-end}
+ARGS=${@:---steps 3 --warmup 2 --settle 0.01 --sectors 360 --no-cpu-baseline --no-end-to-end --no-extras}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p "$OUT"
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -518,27 +518,58 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
     if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; }
 }
 
-// stage 1 of the wire-format launch: as fused_stage1<COLUMN, CH>, but the twiddles are read HERE, behind the butterfly, in
-// two batches of eight (group 0, then group 1).  During the HH task the registers still hold the sector's VV dwords (16 to
-// 32 more live registers than the planar launch has at this point): fifteen twiddles held across both columns, as there,
-// cost 40 spilled registers.  Same arithmetic, same order.
-template <int COLUMN, int CH>
-__device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const float4 (&v)[16], float2 wdv, cf (&g)[8])
+// ---- wire-format input (SURVEY 8f N1): the tile workgroups read the sector as it arrives -------------------------------
+// 12 bytes per sample: hhI hhQ vvI vvQ vhI vhQ, big-endian int16 (sector.cpp:52-62), [1024 rows][512 samples].
+// Lane mapping of the wire-format tile: ONE column (sample) per lane and 32 rows -- lane (c = l & 15, pq = 4 w + (l >> 4))
+// holds the (hh, vv) dwords of rows pq + 32 r, r < 32: an 8-byte load per row at a 12-byte lane stride, so every 128-byte
+// line of a row's 192-byte segment is touched by exactly ONE instruction (two samples per lane, the planar mapping, touch
+// every line twice: 3.30 us/sector non-temporal, 2.96 with the second touch served by the L1 -- and then the input evicts
+// the hand-over slot: WRITE_SIZE 2.3 MB per sector; profiles/r03/ab_wire_input_policy.log).  The even rows r = 2 r' are
+// the sixteen inputs of the radix-16 butterfly of position p0 = pq, the odd ones those of p0 = pq + 32: the lane's two
+// ITEMS (the planar mapping's are two columns at one p0).  ONE set of 64 registers feeds BOTH channel-tasks of the sector,
+// VH is never fetched into a register, byte swap + conversion cost three instructions per sample and channel in stage 1.
+// HBM: 6 MiB per sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
+template <int QUARTER>
+__device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
+                                                    float2 (&v)[32], float &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int pq = w * 4 + (l >> 4), c = l & 15;
+    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * 12u : 0u);
+    const int voff = (pq * DP_N + col_base + c) * 12;
+#pragma unroll
+    for (int rr = QUARTER; rr < 16; rr += 4) {   // rows pq + 64 rr (item 0) and pq + 32 + 64 rr (item 1)
+        v[2 * rr] = buf_load_f2<AUX_NT>(rs, voff, 64 * rr * DP_N * 12);
+        v[2 * rr + 1] = buf_load_f2<AUX_NT>(rs, voff, (64 * rr + 32) * DP_N * 12);
+    }
+    if (QUARTER == 3) {   // the lane's Doppler-window value out of an aligned 16-byte load (element-wise use of a narrower
+                          // buffer load's result is miscompiled by this hipcc: see buf_load_f4)
+        const float4 f = buf_load_f4<0>(make_rsrc(wd, (unsigned)DP_N * 4u), ((col_base + c) & ~3) * 4, 0);
+        wdv = (c & 3) == 0 ? f.x : (c & 3) == 1 ? f.y : (c & 3) == 2 ? f.z : f.w;
+    }
+}
+
+// stage 1 of ITEM (0: position pq, 1: pq + 32) of the lane's column for channel CH; the twiddles are read behind the
+// butterfly in two batches of eight (the registers still hold the other channel's dwords: no room for fifteen)
+template <int ITEM, int CH>
+__device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const float2 (&v)[32], float wdv, cf (&g)[8])
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, cp = l & 7;
-    const int p0 = w * 8 + (l >> 3);
-    const int slot = T::addr(p0, cp) + 8 * COLUMN;
+    const int w = tid >> 6, l = tid & 63, c = l & 15;
+    const int p0 = w * 4 + (l >> 4) + 32 * ITEM;
+    const int slot = T::addr(p0, c >> 1) + 8 * (c & 1);
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
     const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);
     cf a[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float wgt = s_wr[p0 + 64 * r] * (COLUMN ? wdv.y : wdv.x);
-        const cf x = wire_sample(COLUMN ? (CH ? v[r].w : v[r].z) : (CH ? v[r].y : v[r].x));
+        const float wgt = s_wr[p0 + 64 * r] * wdv;
+        const cf x = wire_sample(CH ? v[2 * r + ITEM].y : v[2 * r + ITEM].x);
         a[r] = make_float2(x.x * wgt, x.y * wgt);
     }
     fft16<-1>(a);
@@ -553,37 +584,20 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
 #pragma unroll
     for (int k1 = 8; k1 < 16; k1++) g[k1 - 8] = cmul(a[k1], t[k1 - 8]);
 }
-
-// ---- wire-format input (SURVEY 8f N1): the tile workgroups read the sector as it arrives -------------------------------
-// 12 bytes per sample: hhI hhQ vvI vvQ vhI vhQ, big-endian int16 (sector.cpp:52-62), [1024 rows][512 samples].  A lane
-// takes the (hh, vv) dwords of its two samples of a row with two 8-byte loads; ONE set of 64 registers then feeds BOTH
-// channel-tasks of the sector (the planar form needs one per task), VH is never fetched into a register, and the byte
-// swap + conversion happen in stage 1 in place of nothing (three instructions per sample and channel).  HBM: 6 MiB per
-// sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
-// Cache policy of the wire-format loads.  A lane's two 8-byte loads of a row touch the same one or two 128-byte lines, and
-// so do its neighbours': with plain loads the second touch is served by the CU's L1; non-temporal (as the planar launch's
-// input) every touch goes to the L2 -- 3.30 against 2.96 us/sector (profiles/r03/ab_wire_input_policy.log).
-#ifndef WRP_FUSED_RAW_AUX
-#define WRP_FUSED_RAW_AUX 0
-#endif
-constexpr int FUSED_RAW_AUX = WRP_FUSED_RAW_AUX;
-template <int QUARTER>
-__device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
-                                                    float4 (&v)[16], float2 &wdv, bool valid)
+__device__ __forceinline__ void fused_raw_group1_to_lds(unsigned char *smem, const cf (&g0)[8], const cf (&g1)[8])
 {
-    const int w = wave_id();
-    int l = threadIdx.x & 63;
-    asm volatile("" : "+v"(l));
-    const int p0 = w * 8 + (l >> 3), cp = l & 7;
-    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * 12u : 0u);
-    const int voff = (p0 * DP_N + col_base + cp * 2) * 12;
+    typedef FusedTile T;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= FUSED_THREADS - 1;
+    const int w = tid >> 6, l = tid & 63, c = l & 15;
+    const int pq = w * 4 + (l >> 4);
+    const int slot = T::addr(pq, c >> 1) + 8 * (c & 1);
 #pragma unroll
-    for (int r = QUARTER; r < 16; r += 4) {
-        const float2 a = buf_load_f2<FUSED_RAW_AUX>(rs, voff, 64 * r * DP_N * 12);
-        const float2 b = buf_load_f2<FUSED_RAW_AUX>(rs, voff + 12, 64 * r * DP_N * 12);
-        v[r] = make_float4(a.x, a.y, b.x, b.y);
+    for (int j = 0; j < 8; j++) {
+        *reinterpret_cast<float2 *>(smem + slot + j * 8 * T::BLK_BYTES) = g0[j];
+        *reinterpret_cast<float2 *>(smem + slot + j * 8 * T::BLK_BYTES + 4 * T::BLK_BYTES) = g1[j];   // position + 32 = four blocks on
     }
-    if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
 // The tile member of the wire-format launch: the loop of fused_chain_1024x512's tile member with the two channel-tasks of
@@ -598,8 +612,8 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
     auto tile_col = [&](int sec) { return ((rank + sec) & (FUSED_MEMBERS - 1)) * 16; };
     auto sector_src = [&](int sec) { return raw + (size_t)(trank + sec * teams) * RP_M * DP_N * 3; };
     const int sectors = tasks >> 1;
-    float4 v[16];
-    float2 wdv;
+    float2 v[32];
+    float wdv;
     fused_raw_tile_load<0>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
     fused_raw_tile_load<1>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
     fused_raw_tile_load<2>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
@@ -637,7 +651,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         fused_store(mid, col, 0, o);
         __builtin_amdgcn_sched_barrier(0);
         if (CH) fused_raw_tile_load<2>(next, next_col, rc.wd, v, wdv, more);
-        fused_group1_to_lds(smem, ga, gc);
+        fused_raw_group1_to_lds(smem, ga, gc);
         if (CH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 requests just issued: the stores are in the L2
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         last = 0;
