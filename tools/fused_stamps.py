@@ -25,21 +25,33 @@ def main():
     import wrp_amd
     from oracle import oracle as O
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    zeros = len(sys.argv) > 2 and sys.argv[2] == "zeros"      # an all-zero sweep: same instructions, no switching in the data paths
     dev = torch.device("cuda", 0)
     pool = np.stack([O.synthetic_sector(k) for k in range(2)])
     d_pool = torch.from_numpy(pool.view(np.float32).reshape(2, -1)).to(dev)
     d_iq = d_pool[torch.arange(S, device=dev) % 2].contiguous()
+    if zeros:
+        d_iq.zero_()
     d_out = torch.empty((S, 512, 2), dtype=torch.float32, device=dev)
     eng = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1)
     nwg = torch.cuda.get_device_properties(0).multi_processor_count * 2
     st = np.zeros((nwg, 16, 9), np.uint64)
     lib = eng.lib
+    import time
+    t_end = time.perf_counter() + 2.0      # the chip at its working point: two seconds of launches on this data first
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            eng.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
+        eng.check()
     for _ in range(2):
         rc = lib.wrp_debug_fused_stamps(eng.handle, C.c_void_p(d_iq.data_ptr()), S, C.c_void_p(d_out.data_ptr()),
                                         st.ctypes.data_as(C.c_void_p), st.size)
         assert rc == 0, (rc, lib.wrp_last_hip_error(eng.handle))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "stamps.npy"), st)
+    clk = st[:, 1, 8].astype(np.float64) / np.maximum(st[:, 2, 8].astype(np.float64), 1.0) * 100.0     # MHz
+    print(f"shader clock over the task loop ({'ALL-ZERO input' if zeros else 'synthetic input'}): median {np.median(clk):.0f} MHz "
+          f"(p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f}); launch {np.median(st[:, 2, 8]) / 100.0:.1f} us")
     ident = st[:, 0, 8]
     kind = (ident >> np.uint64(32)).astype(int)
     xcc = ((ident >> np.uint64(16)) & np.uint64(0xffff)).astype(int)

@@ -74,7 +74,8 @@ def source_fingerprint():
 
 
 def lib_path():
-    return os.path.join(_PKG, "lib", "libwrp.so")
+    # WRP_LIB_PATH: measurement tools load an experimental build in place of the product's (tools/ only; no test sets it)
+    return os.environ.get("WRP_LIB_PATH") or os.path.join(_PKG, "lib", "libwrp.so")
 
 
 def header_symbols():

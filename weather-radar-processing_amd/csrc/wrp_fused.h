@@ -81,10 +81,28 @@ constexpr int FUSED_STAMP_TASKS = 16;
 #ifndef WRP_FUSED_ROW_SPLIT
 #define WRP_FUSED_ROW_SPLIT 1       // 1: every row wave serves both halves, one row of each; 0: four waves per half, two rows each
 #endif
+#ifndef WRP_FUSED_INPUT_AUX
+#define WRP_FUSED_INPUT_AUX 2       // cache policy of the planar input loads: AUX_NT
+#endif
+// How the next tile is requested (profiles/r03/ab_request_pacing.log; us/sector in one process, builds interleaved):
+//   0: in QUARTERS (4 loads per lane at 4 points of the task: round 2)        2.465
+//   1: in EIGHTHS  (2 loads at 8 points)                                      2.353
+//   2: ONE load at a time, sixteen pieces over twelve points of the task      2.330   <- kept
+// The launch with its loads dropped by a zero-record descriptor runs at 1.74: what the input costs is not HBM time (tiles
+// served by the Infinity Cache: 2.39) and not a wait for the data (stage 1 starts on time in either build) -- the tile
+// waves stall where they ISSUE a burst of requests into a CU memory pipeline that holds a bounded number of misses
+// (profiles/r03/fused_stamps_loads_vs_noloads.log: the phases that contain request points grow, the others do not).
+#ifndef WRP_FUSED_EIGHTHS
+#define WRP_FUSED_EIGHTHS 2
+#endif
+#ifndef WRP_FUSED_CU_KINDS
+#define WRP_FUSED_CU_KINDS 0        // 1: tile CUs and row CUs (two workgroups of ONE kind per CU); 0: a tile and a row workgroup on every CU
+#endif
 #ifndef WRP_FUSED_ROW_POLLERS
 #define WRP_FUSED_ROW_POLLERS 0     // 1: one wave per half polls the L2 and wakes the other three (measured slower: above)
 #endif
 constexpr unsigned long long FUSED_JOIN_TICKS = 400000ull;   // 4 ms of s_memrealtime (100 MHz): deadline of the team meeting
+constexpr int FUSED_INPUT_AUX = WRP_FUSED_INPUT_AUX;
 constexpr int FUSED_POLL_SLEEP = WRP_FUSED_POLL_SLEEP;   // s_sleep units (64 cycles) between two polls of a row wave
 constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (task 0)
 constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the gates of ONE half
@@ -103,7 +121,7 @@ struct FusedCtl {               // zeroed by the host once; every launch leaves 
     unsigned pad0[30];
     unsigned census[2][8];      // workgroups per kind (0 tile, 1 row) and XCC
     unsigned done[8];           // workgroups of the XCC's team that have left the task loop
-    unsigned pad1[8];
+    unsigned cu_count[8];       // (WRP_FUSED_CU_KINDS) CUs of the XCC seen so far: a CU's ordinal decides the kind of BOTH its workgroups
     unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
     unsigned cu_block[8][256][2];            // blockIdx + 1 of the first and the second workgroup to arrive there
     FusedFlags stored[2][8][FUSED_MEMBERS];  // [half][xcc][line of row member r]: byte t = tasks whose half tile member t has stored
@@ -270,11 +288,44 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));   // recompute the lane offsets per call instead of keeping (spilling) them
     const int p0 = w * 8 + (l >> 3), cp = l & 7;
+#ifdef WRP_EXP_NOLOAD   // timing only: what the launch costs without its input (results are wrong)
+    valid = false;
+#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
     const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
 #pragma unroll
-    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<AUX_NT>(rs, voff, 64 * r * DP_N * 8);
+    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * r * DP_N * 8);
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
+}
+
+// ONE row load (WRP_FUSED_EIGHTHS == 2: sixteen pieces over twelve request points)
+template <int R>
+__device__ __forceinline__ void fused_tile_load1(const float2 *src /* wave-uniform */, int col_base, const float *wd,
+                                                 float4 (&v)[16], float2 &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int p0 = w * 8 + (l >> 3), cp = l & 7;
+    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
+    const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
+    v[R] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * R * DP_N * 8);
+    if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
+}
+// an EIGHTH: rows r = E and E + 8 (WRP_FUSED_EIGHTHS: eight request points per task instead of four)
+template <int E>
+__device__ __forceinline__ void fused_tile_load8(const float2 *src /* wave-uniform */, int col_base, const float *wd,
+                                                 float4 (&v)[16], float2 &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int p0 = w * 8 + (l >> 3), cp = l & 7;
+    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
+    const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
+    v[E] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * E * DP_N * 8);
+    v[E + 8] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * (E + 8) * DP_N * 8);
+    if (E == 7) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
 // stage 1 (a2 + first radix of a3): window, radix 16 over rows p0 + 64 r, twiddle W_1024^{p0 k1};
@@ -357,7 +408,10 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
 // k1 + 16 k2 + 128 k3 (k1 = w + 8 group, k2 = (l >> 4) + 4 it, k3 < 4) of column col; the chain never
 // reads the other half of the gates (rpv2.cu:502).  Stores are plain: the lines stay in the XCD's
 // L2, where the row members find them; 16 lanes x 8 bytes = one whole 128-byte line per gate.
-__device__ __forceinline__ void fused_stage2(unsigned char *smem)
+// stages 2 and 3 are written per ITEM (two per lane and stage) so that the launch can place a request for the next tile
+// between any two of them
+template <int IT>
+__device__ __forceinline__ void fused_stage2_item(unsigned char *smem)
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
@@ -365,24 +419,28 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;   // position w*64 of this lane's column
+    // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
+    const int p1 = (l >> 4) + 4 * IT;
+    cf a[8], t[8];   // the seven twiddles in one batch with the data, not one LDS round trip each
 #pragma unroll
-    for (int it = 0; it < 2; it++) {   // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
-        const int p1 = (l >> 4) + 4 * it;
-        cf a[8], t[8];   // the seven twiddles in one batch with the data, not one LDS round trip each
+    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
 #pragma unroll
-        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
+    for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
+    fft8<-1>(a);
+    *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) t[k2] = *reinterpret_cast<const float2 *>(smem + T::tw2_addr(p1, k2));
-        fft8<-1>(a);
-        *reinterpret_cast<float2 *>(base + p1 * T::ROW_BYTES) = a[0];
-#pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t[k2]);
-    }
+    for (int k2 = 1; k2 < 8; k2++) *reinterpret_cast<float2 *>(base + k2 * T::BLK_BYTES + p1 * T::ROW_BYTES) = cmul(a[k2], t[k2]);
     // (both items' reads in one batch, the second item's twiddles read under the first item's butterfly -- two LDS round
     // trips in the open instead of four, 128 registers -- measured the same in the launch: profiles/r03/ab_stage23_interleaved.log)
-    wave_lds_fence();
+    if (IT == 1) wave_lds_fence();
 }
-__device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
+__device__ __forceinline__ void fused_stage2(unsigned char *smem)
+{
+    fused_stage2_item<0>(smem);
+    fused_stage2_item<1>(smem);
+}
+template <int IT>
+__device__ __forceinline__ void fused_stage3_item(unsigned char *smem, cf (&o)[2][4])
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
@@ -390,16 +448,18 @@ __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
+    const int k2 = (l >> 4) + 4 * IT;     // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
+    cf a[8];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {   // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
-        const int k2 = (l >> 4) + 4 * it;
-        cf a[8];
+    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
+    fft8<-1>(a);
 #pragma unroll
-        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
-        fft8<-1>(a);
-#pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];
-    }
+    for (int k3 = 0; k3 < 4; k3++) o[IT][k3] = a[k3];
+}
+__device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
+{
+    fused_stage3_item<0>(smem, o);
+    fused_stage3_item<1>(smem, o);
 }
 __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
 {
@@ -451,7 +511,28 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
                 if (!other) __builtin_amdgcn_s_sleep(4);
             }
         }
+#if WRP_FUSED_CU_KINDS
+        // Specialised CUs: the first sixteen CUs of the XCD to report host two TILE workgroups each, the others two ROW
+        // workgroups.  (A CU's vector-memory pipeline is in order: beside a tile workgroup's HBM requests the L2 hits of the
+        // row workgroup -- which are in the hand-over chain every tile member waits for -- queue behind them.)
+        unsigned kind = a & 1u;
+        if (a == 0) {
+            const unsigned ord = __hip_atomic_fetch_add(&ctl->cu_count[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&ctl->cu_block[x][key][0], 0x80000000u | ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            kind = ord < (unsigned)FUSED_MEMBERS / 2 ? 0u : 1u;
+        } else if (a == 1 && other) {
+            unsigned first = other;       // what the first arriver left there: its block id, then 0x80000000 | ordinal
+#pragma unroll 1
+            while (!(first & 0x80000000u) && __builtin_amdgcn_s_memrealtime() - t_join < FUSED_JOIN_TICKS) {
+                first = __hip_atomic_load(&ctl->cu_block[x][key][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(first & 0x80000000u)) __builtin_amdgcn_s_sleep(4);
+            }
+            if (!(first & 0x80000000u)) other = 0;
+            kind = (first & 0x7fffffffu) < (unsigned)FUSED_MEMBERS / 2 ? 0u : 1u;
+        }
+#else
         const unsigned kind = other ? (blockIdx.x + 1u < other ? 0u : 1u) : (a & 1u);
+#endif
         const unsigned rank = __hip_atomic_fetch_add(&ctl->census[kind][x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned teams = gridDim.x / (2u * FUSED_MEMBERS);
         int good = other != 0 && x < teams && gridDim.x == teams * 2u * FUSED_MEMBERS;
@@ -515,7 +596,7 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
     for (int e = tid; e < 256 / 4; e += FUSED_THREADS) z[e] = zero;
     z = reinterpret_cast<uint4 *>(ctl->cu_block[xcc]);
     for (int e = tid; e < 512 / 4; e += FUSED_THREADS) z[e] = zero;
-    if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; }
+    if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; ctl->cu_count[xcc] = 0; }
 }
 
 // ---- wire-format input: the tile workgroups read the sector as it arrives -------------------------------
@@ -529,6 +610,24 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
 // ITEMS (the planar mapping's are two columns at one p0).  ONE set of 64 registers feeds BOTH channel-tasks of the sector,
 // VH is never fetched into a register, byte swap + conversion cost three instructions per sample and channel in stage 1.
 // HBM: 6 MiB per sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
+// ONE piece of the wire-format tile: the rows pq + 64 RR and pq + 32 + 64 RR (sixteen pieces, requested one at a time)
+template <int RR>
+__device__ __forceinline__ void fused_raw_tile_load1(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
+                                                     float2 (&v)[32], float &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int pq = w * 4 + (l >> 4), c = l & 15;
+    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * 12u : 0u);
+    const int voff = (pq * DP_N + col_base + c) * 12;
+    v[2 * RR] = buf_load_f2<AUX_NT>(rs, voff, 64 * RR * DP_N * 12);
+    v[2 * RR + 1] = buf_load_f2<AUX_NT>(rs, voff, (64 * RR + 32) * DP_N * 12);
+    if (RR == 15) {
+        const float4 f = buf_load_f4<0>(make_rsrc(wd, (unsigned)DP_N * 4u), ((col_base + c) & ~3) * 4, 0);
+        wdv = (c & 3) == 0 ? f.x : (c & 3) == 1 ? f.y : (c & 3) == 2 ? f.z : f.w;
+    }
+}
 template <int QUARTER>
 __device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
                                                     float2 (&v)[32], float &wdv, bool valid)
@@ -642,15 +741,21 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         fused_stage1_raw<1, CH>(smem, v, wdv, gc);
         __syncthreads();                    // A1
         cf o[2][4];
-        if (CH) fused_raw_tile_load<0>(next, next_col, rc.wd, v, wdv, more);
-        fused_stage2(smem);
-        if (CH) fused_raw_tile_load<1>(next, next_col, rc.wd, v, wdv, more);
-        fused_stage3(smem, o);
+#define WRP_LR(RR) if (CH) fused_raw_tile_load1<RR>(next, next_col, rc.wd, v, wdv, more)
+        WRP_LR(0); WRP_LR(8);
+        fused_stage2_item<0>(smem);
+        WRP_LR(4);
+        fused_stage2_item<1>(smem);
+        WRP_LR(12);
+        fused_stage3_item<0>(smem, o);
+        WRP_LR(1);
+        fused_stage3_item<1>(smem, o);
+        WRP_LR(9);
         spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
         __syncthreads();                    // A2
         fused_store(mid, col, 0, o);
         __builtin_amdgcn_sched_barrier(0);
-        if (CH) fused_raw_tile_load<2>(next, next_col, rc.wd, v, wdv, more);
+        WRP_LR(5); WRP_LR(13); WRP_LR(2); WRP_LR(10);
         fused_raw_group1_to_lds(smem, ga, gc);
         if (CH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 requests just issued: the stores are in the L2
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -658,9 +763,16 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
         if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
         __syncthreads();                    // A3
-        if (CH) fused_raw_tile_load<3>(next, next_col, rc.wd, v, wdv, more);
-        fused_stage2(smem);
-        fused_stage3(smem, o);
+        WRP_LR(6);
+        fused_stage2_item<0>(smem);
+        WRP_LR(14);
+        fused_stage2_item<1>(smem);
+        WRP_LR(3);
+        fused_stage3_item<0>(smem, o);
+        WRP_LR(11);
+        fused_stage3_item<1>(smem, o);
+        WRP_LR(7); WRP_LR(15);
+#undef WRP_LR
         spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
         __syncthreads();                    // A4
         fused_store(mid, col, 1, o);
@@ -714,8 +826,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         __syncthreads();
         if (tid == 0) s_stamps[FUSED_STAMPS - 1] = ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
     }
+    // diagnostics build: the shader clock this workgroup saw over its task loop = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    // (slot 8 of tasks 1 and 2): the launch is clock-limited by the power its DATA draws
+    const unsigned long long clk_t0 = STAMPS ? __builtin_amdgcn_s_memtime() : 0, clk_r0 = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0;
     auto flush_stamps = [&]() {
         if (STAMPS && stamps) {
+            if (tid == 0) {
+                s_stamps[1 * FUSED_STAMPS + FUSED_STAMPS - 1] = __builtin_amdgcn_s_memtime() - clk_t0;
+                s_stamps[2 * FUSED_STAMPS + FUSED_STAMPS - 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+            }
             __syncthreads();
             for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS)
                 stamps[(size_t)blockIdx.x * FUSED_STAMP_TASKS * FUSED_STAMPS + e] = s_stamps[e];
@@ -733,7 +852,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         // member: rotating the tiles makes that a transient of each member, which the slack of the
         // hand-overs absorbs, instead of four members that are always late.
         auto tile_col = [&](int q) { return ((rank + q) & (FUSED_MEMBERS - 1)) * 16; };
+#ifdef WRP_EXP_KEEPV    // timing only: the first tile stays in the registers for the whole launch -- real data, no requests
+#define WRP_KEEPV_OFF(x) (void)next
+#else
+#define WRP_KEEPV_OFF(x) x
+#endif
+#ifdef WRP_EXP_L2LOAD   // timing only: every tile comes from the SAME sector of the team (L2 / Infinity Cache hits, real data)
+        auto tile_src = [&](int q) { return iq + ((size_t)trank * channels + (q & 1)) * RP_M * (size_t)n; };
+#else
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
+#endif
         float4 v[16];
         float2 wdv;
         fused_tile_load<0>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);   // HBM requests first ...
@@ -776,10 +904,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             // v is free: the next tile is requested a quarter at a time over the rest of this one
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
             cf o[2][4];
-            fused_tile_load<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+#define WRP_L1(R) fused_tile_load1<R>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks)
+#if WRP_FUSED_EIGHTHS == 2
+            WRP_L1(0); WRP_L1(8);
+            fused_stage2_item<0>(smem);
+            WRP_L1(4);
+            fused_stage2_item<1>(smem);
+            WRP_L1(12);
+            fused_stage3_item<0>(smem, o);
+            WRP_L1(1);
+            fused_stage3_item<1>(smem, o);
+            WRP_L1(9);
+#elif WRP_FUSED_EIGHTHS
+            fused_tile_load8<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage2(smem);
-            fused_tile_load<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+            fused_tile_load8<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
             fused_stage3(smem, o);
+            fused_tile_load8<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+#else
+            WRP_KEEPV_OFF(fused_tile_load<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
+            fused_stage2(smem);
+            WRP_KEEPV_OFF(fused_tile_load<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
+            fused_stage3(smem, o);
+#endif
             // The team's ONE slot (1 MiB: the 256 gates of a half x 512 pulses) takes half 0 and half 1 of every task in
             // turn; it still holds half 1 of task q-1 until every row member has those rows in registers.  One slot
             // instead of one per half: a rewritten buffer of 2 MiB per XCD does not stay in the 4 MiB L2 beside the
@@ -793,10 +940,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             // BEHIND the stores, so that a counted wait can tell them apart: the scheduling barrier keeps the four loads
             // below the eight stores whatever alias analysis says about `iq` (restrict) and the descriptor
             __builtin_amdgcn_sched_barrier(0);
-            fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+#if WRP_FUSED_EIGHTHS == 2
+            WRP_L1(5); WRP_L1(13); WRP_L1(2); WRP_L1(10);
+#elif WRP_FUSED_EIGHTHS
+            fused_tile_load8<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+            fused_tile_load8<4>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+#else
+            WRP_KEEPV_OFF(fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
+#endif
             fused_group1_to_lds(smem, ga, gc);
             stamp(q, 2);
+#ifdef WRP_EXP_KEEPV
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
+#endif
             // ... and counted by the last wave to get here, without waiting for the barrier
             last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
@@ -804,9 +962,27 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             stamp(q, 6);
             __syncthreads();                    // A3: group 1 is in the image
             stamp(q, 3);
-            fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+#if WRP_FUSED_EIGHTHS == 2
+            WRP_L1(6);
+            fused_stage2_item<0>(smem);
+            WRP_L1(14);
+            fused_stage2_item<1>(smem);
+            WRP_L1(3);
+            fused_stage3_item<0>(smem, o);
+            WRP_L1(11);
+            fused_stage3_item<1>(smem, o);
+            WRP_L1(7); WRP_L1(15);
+#elif WRP_FUSED_EIGHTHS
+            fused_tile_load8<5>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage2(smem);
+            fused_tile_load8<6>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+            fused_stage3(smem, o);
+            fused_tile_load8<7>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
+#else
+            WRP_KEEPV_OFF(fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
             fused_stage2(smem);
             fused_stage3(smem, o);
+#endif
             spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             stamp(q, 7);
             __syncthreads();                    // A4: image free for the next stage 1; the slot is free for half 1 (the rows have half 0 of THIS task)
@@ -855,7 +1031,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
                 if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
                 if (g == 0) stamp(q, 2);
+#ifdef WRP_EXP_NOROW    // timing only: the rows are loaded and handed back, not transformed
+                const float s = x[0].x + x[7].y;
+#else
                 const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
+#endif
                 if (g == 0) stamp(q, 3);
                 if ((q & 1) == 0) s_hh[g] = s;
                 else if (l == 0) reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh[g], s, k_rr, k_cal);

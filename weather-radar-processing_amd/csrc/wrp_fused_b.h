@@ -86,6 +86,24 @@ __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-unif
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
+// ONE row load of the next tile (rows p0 + 128 R): the tile is requested a piece at a time over the task, see wrp_fused.h
+template <int R>
+__device__ __forceinline__ void fused_b_tile_load1(const float2 *src /* wave-uniform */, int col_base, const float *wd,
+                                                   float4 (&v)[16], float2 &wdv, bool valid)
+{
+    const int w = wave_id();
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int p0 = w * 16 + (l >> 2), cp = l & 3;
+#ifdef WRP_EXP_B_NOLOAD
+    valid = false;
+#endif
+    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
+    const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
+    v[R] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8);
+    if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
+}
+
 __device__ __forceinline__ void fused_b_stage1_tables(const unsigned char *smem, cf (&tw)[16])
 {
     typedef FusedTileB T;
@@ -274,24 +292,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
             const bool more = q + 1 < tasks;
             cf o[2][4];
-            fused_b_tile_load<0>(next, col_base, rc.wd, v, wdv, more);
+#define WRP_LB(R) fused_b_tile_load1<R>(next, col_base, rc.wd, v, wdv, more)
+            WRP_LB(0); WRP_LB(8);
             fused_b_stage2(smem);
-            fused_b_tile_load<1>(next, col_base, rc.wd, v, wdv, more);
+            WRP_LB(4); WRP_LB(12);
             fused_b_stage3(smem, o);
+            WRP_LB(1); WRP_LB(9);
             spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_b_store(mid, ch, col_base, o);
             __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
-            fused_b_tile_load<2>(next, col_base, rc.wd, v, wdv, more);
+            WRP_LB(5); WRP_LB(13); WRP_LB(2); WRP_LB(10);
             fused_b_group1_to_lds(smem, ga, gc);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
             int last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
             if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
             __syncthreads();                    // A3: group 1 is in the image
-            fused_b_stage2(smem);
-            fused_b_tile_load<3>(next, col_base, rc.wd, v, wdv, more);   // behind stage 2: its sixteen points + fifteen twiddles need the registers
+            WRP_LB(6);
+            fused_b_stage2(smem);      // (its sixteen points + fifteen twiddles need registers: most of the rest is requested behind it)
+            WRP_LB(14); WRP_LB(3);
             fused_b_stage3(smem, o);
+            WRP_LB(11); WRP_LB(7); WRP_LB(15);
+#undef WRP_LB
             spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
             fused_b_store(mid, ch, col_base, o);
