@@ -307,6 +307,9 @@ __device__ __forceinline__ void fused_tile_load1(const float2 *src /* wave-unifo
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int p0 = w * 8 + (l >> 3), cp = l & 7;
+#ifdef WRP_EXP_NOLOAD
+    valid = false;
+#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
     const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
     v[R] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * R * DP_N * 8);

@@ -5,14 +5,14 @@
 //   doppler_pass_512  : mean removal (a4), Doppler FFT + conj + shift + clip (a5), |.|^2 (a6),
 //                       7-tap causal circular MA (a7), row sum (a8), Zdb/Zdr (a9); one wave per
 //                       range gate, both polarisations in the same wave.
-//   (wrp_fused.h, wrp_fused_roles.h: both passes in ONE persistent launch whose XCD teams keep the
-//    2 MiB intermediate of a sector-channel in that XCD's L2; opt-in.)
+//   (wrp_fused.h / wrp_fused_b.h: the same device functions inside ONE persistent launch whose XCD teams keep the
+//    half-height intermediate of a sector in that XCD's L2 -- the default for batches of >= 8 sectors.)
 //
 // Reference semantics: read.cc:133-345 / rpv2.cu:86-213,409-570 (DESIGN.md §1 maps every stage).
 // No rocFFT/hipFFT: the FFTs are LDS-resident mixed-radix passes (16x8x8 for m = 1024, 8x8x8 for
-// n = 512) built from fft_radix.h.  All forms of a pass share the device functions below and the
-// library is built with -ffp-contract=off, so they are bit-identical to each other (the fused
-// launches factor the range FFT 8x16x8 and agree with the two kernels to rounding).
+// n = 512) built from fft_radix.h.  All forms of a pass share the device functions below, factor the
+// transforms the same way and the library is built with -ffp-contract=off, so they are bit-identical to
+// each other (tests/test_gpu_parity.py).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,7 +1,8 @@
 """Sector sharding across GPUs: sectors are independent, so a volume scan is split by
-sector index with NO data-path collective.  torch.distributed (RCCL on GPUs, gloo in the CPU
-tests) is used only for the barrier, the MAX of the elapsed time and -- optionally -- gathering
-the per-rank result tables on rank 0 (control plane, 4 KiB per sector)."""
+sector index with NO data-path collective.  torch.distributed (gloo on CPU tensors, on the GPU box
+and in the CPU tests alike: RCCL is never initialised) is used only for the barrier, the MAX of the
+elapsed time and -- optionally -- gathering the per-rank result tables on rank 0 (control plane,
+4 KiB per sector)."""
 
 
 def sectors_for_rank(n_sectors, rank, world):
