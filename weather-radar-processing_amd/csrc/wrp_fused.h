@@ -1028,6 +1028,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 if (!there) break;                              // status is set: the launch is void
                 if (g == 0) stamp(q, 1);
                 cf x[8];
+                // (slot rows in the order the lanes read them -- pulses l + 128 k and l + 64 + 128 k side by side, four
+                // 16-byte loads per lane instead of eight 8-byte ones -- cost the tile members scattered 8-byte stores and
+                // were 0.8 % slower: profiles/r03/ab_paired_slot_rows.log)
                 doppler_load_row<AUX_SC1>(mid + (size_t)r0 * n, l, x);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row in registers: the slot may be overwritten
                 int last = 0;
