@@ -298,22 +298,26 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
-// ONE row load (WRP_FUSED_EIGHTHS == 2: sixteen pieces over twelve request points)
-template <int R>
-__device__ __forceinline__ void fused_tile_load1(const float2 *src /* wave-uniform */, int col_base, const float *wd,
-                                                 float4 (&v)[16], float2 &wdv, bool valid)
+// ONE row load (WRP_FUSED_EIGHTHS == 2: sixteen pieces over twelve request points).  The lane offset of the tile is computed
+// ONCE per task (fused_tile_voff) and kept in a register: recomputed at each of the sixteen points it was 6 % of the
+// launch's vector instructions.
+__device__ __forceinline__ int fused_tile_voff(int col_base)
 {
     const int w = wave_id();
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
-    const int p0 = w * 8 + (l >> 3), cp = l & 7;
+    return ((w * 8 + (l >> 3)) * DP_N + col_base + (l & 7) * 2) * 8;
+}
+template <int R>
+__device__ __forceinline__ void fused_tile_load1(const float2 *src /* wave-uniform */, int voff, const float *wd,
+                                                 float4 (&v)[16], float2 &wdv, bool valid)
+{
 #ifdef WRP_EXP_NOLOAD
     valid = false;
 #endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
-    const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
     v[R] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * R * DP_N * 8);
-    if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
+    if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (voff & (DP_N * 8 - 1)) >> 1, 0);   // (col_base + 2 cp) * 4
 }
 // an EIGHTH: rows r = E and E + 8 (WRP_FUSED_EIGHTHS: eight request points per task instead of four)
 template <int E>
@@ -907,7 +911,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             // v is free: the next tile is requested a quarter at a time over the rest of this one
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
             cf o[2][4];
-#define WRP_L1(R) fused_tile_load1<R>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks)
+            const int voff_next = fused_tile_voff(tile_col(q + 1));
+#define WRP_L1(R) fused_tile_load1<R>(next, voff_next, rc.wd, v, wdv, q + 1 < tasks)
 #if WRP_FUSED_EIGHTHS == 2
             WRP_L1(0); WRP_L1(8);
             fused_stage2_item<0>(smem);
