@@ -20,14 +20,14 @@
 // 32 tile members + 32 row members; a team meets once (its census), teams never talk to each
 // other.  Team e owns sectors e, e + teams, ...; a sector is two channel-TASKS q = 0, 1, 2, ...
 //   tile member r : range tile (r + q) mod 32 (16 columns) of task q  -> the team's ONE 1 MiB slot
-//   row member r  : gates 16 r .. 16 r + 15 of every task (wave w: gates 16 r + 2 w, + 1), a4 .. a9
+//   row member r  : gates 16 r .. 16 r + 15 of every task (wave w: gate 16 r + w of half 0 and 16 r + 8 + w of half 1), a4 .. a9
 // Hand-offs.  A task goes through the slot in two HALVES g = 0, 1 -- the gates with (gate mod 16) in
 // [8 g, 8 g + 8), which is exactly what k1-group g of a tile produces (see below); gate -> slot row
 // (gate >> 4) * 8 + (gate & 7).  Each half has its own pair of flag arrays:
 //   stored[g] : a tile member publishes "half g of q tasks stored" once its stores have drained; a row
 //               member waits until all 32 tile members have published the task it wants
-//   loaded[g] : a row member publishes once its 8 rows of the half are in registers; a tile member waits for
-//               all 32 before it puts the next half into the slot
+//   loaded[g] : a row member publishes once its 8 rows of the half are in registers (one per wave); a tile member
+//               waits for all 32 before it puts the next half into the slot
 // A tile member stores half 0 in the middle of a tile and half 1 at its end; while the rows of one
 // half are loaded and transformed the tile members compute the other half.  (Two slots, one per half,
 // give each hand-over a whole task of slack -- and were no faster: 2 MiB rewritten per XCD do not stay
@@ -1005,11 +1005,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         fused_leave(ctl, host_status, xcc, s_ctl);
     } else {
         // =============================== row member ===============================
-        // Eight independent waves, no workgroup barrier in the loop: waves 0-3 own the member's 8 gates
-        // of half 0 (two each), waves 4-7 those of half 1, so a wave has a whole task period for its
-        // two rows and the halves do not wait for each other.  A wave polls the member's replica
-        // itself (scalar loads); the last of a half's four waves to have its rows in registers
-        // (counted in LDS) counts the member as loaded.
+        // Eight independent waves, no workgroup barrier in the loop.  A wave polls the member's flag line itself (scalar
+        // loads); the last of a half's waves to have its row(s) in registers (counted in LDS) counts the member as loaded.
+        // WRP_FUSED_ROW_SPLIT (default): every wave serves both halves, one gate each; 0: waves 0-3 own the member's 8
+        // gates of half 0 (two each), waves 4-7 those of half 1.
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         doppler_twiddles_to_lds(s_twn, tw_n, tid, FUSED_THREADS);
