@@ -123,13 +123,42 @@ def cpu_baseline(m=1024, n=512):
                       "oracle/radar_oracle.c fp32 port" % ("/".join(str(r["sectors"]) for _, r in runs.values()), t16, physical)}
 
 
+class RankControl:
+    """Barrier and MAX over the ranks of one node through torch.distributed's TCP store (the launcher's own store under
+    torch.distributed.run, else one that rank 0 hosts on MASTER_ADDR:MASTER_PORT)."""
+
+    def __init__(self, rank, world):
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29533"))
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False").lower() == "true"
+        self.store = TCPStore(host, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=900),
+                              wait_for_workers=False)
+        self.rank, self.world, self.n = rank, world, 0
+
+    def barrier(self):
+        self.n += 1
+        key = "wrp/bench/%d" % self.n
+        if self.store.add(key, 1) == self.world:
+            self.store.set(key + "/go", "1")
+        self.store.wait([key + "/go"])
+
+    def max(self, x):
+        self.n += 1
+        key = "wrp/bench/%d" % self.n
+        self.store.set("%s/%d" % (key, self.rank), repr(float(x)))
+        self.barrier()
+        return max(float(self.store.get("%s/%d" % (key, r)).decode()) for r in range(self.world))
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes with torch.distributed.run BEFORE this
     process has touched a GPU, relay rank 0's JSON line and exit with the launcher's code."""
     import socket
     import torch
     have = torch.cuda.device_count()            # counts devices without initialising the GPU
-    if have < n:
+    if have < n and not os.environ.get("WRP_BENCH_OVERSUBSCRIBE"):      # (rehearsal of the N-rank plumbing on a smaller box)
         sys.exit("bench.py: --gpus %d asked for, %d GPU(s) visible" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -171,7 +200,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    ctl = None
     ngpu = torch.cuda.device_count()
     if ngpu < world and not os.environ.get("WRP_BENCH_OVERSUBSCRIBE"):
         sys.exit("bench.py: %d ranks but %d GPU(s) visible (WRP_BENCH_OVERSUBSCRIBE=1 rehearses on a smaller box)" % (world, ngpu))
@@ -179,13 +208,10 @@ def main():
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        # control plane only (barrier + MAX of the elapsed time): gloo on CPU tensors; the data path has
-        # no collective and RCCL is never initialised (north_star)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # control plane only (barrier + MAX of the elapsed time) over torch.distributed's TCP store: the data path has no
+        # collective, RCCL is never initialised (north_star), and no process group is created (gloo announces its
+        # connections on STDOUT, in front of the one JSON line this program owes its caller)
+        ctl = RankControl(rank, world)
 
     m, n, C = (1024, 512, 2) if args.shape == "A" else (2048, 128, 2)
     S = args.sectors
@@ -211,16 +237,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if ctl is not None:
+            ctl.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return x if ctl is None else ctl.max(x)
 
     def settle(seconds=None):
         seconds = args.settle if seconds is None else seconds
@@ -429,9 +451,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(m, n)
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctl is not None:
+        ctl.barrier()
     if rank == 0:
         print(json.dumps(line), flush=True)
 

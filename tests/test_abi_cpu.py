@@ -85,3 +85,40 @@ def test_source_fingerprint_ignores_comments_and_layout_only():
     import wrp_amd
     fp = wrp_amd.source_fingerprint()
     assert len(fp) == 16 and fp == wrp_amd.source_fingerprint()
+
+
+def test_counted_wait_of_the_fused_launch_sees_its_stores_before_its_loads(tmp_path):
+    """The tile members publish `stored[0]` behind `s_waitcnt vmcnt(N)`: correct only if, in PROGRAM ORDER between the
+    barrier A2 and that wait, the eight slot stores come first and exactly N request(s) for the next tile follow them
+    (a load hoisted above a store would let the flag overtake the data: a silent race).  Checked on the disassembly of
+    every fused kernel the library is built from, with the Makefile's flags."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = next(l for l in open(os.path.join(root, "Makefile")) if l.startswith("HIPFLAGS")).split("?=")[1].split()
+    flags = [f.replace("$(ARCH)", "gfx950") for f in flags if f != "-fPIC"]
+    asm = tmp_path / "engine.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", "-o", str(asm),
+                           os.path.join(root, "weather-radar-processing_amd", "csrc", "wrp_engine.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    checked = 0
+    for name, body in re.findall(r"^(_ZN3wrp20fused_chain_\w+):.*?\n(.*?)\.amdhsa_kernel", text, flags=re.S | re.M):
+        if "Lb1ELb0EEE" in name and "1024x512" in name:
+            continue                      # the stamps instantiation: s_memrealtime loads sit between the stores and the wait
+        ops = [l.split()[0] + (" " + l.split("vmcnt(")[1].split(")")[0] if "vmcnt(" in l else "")
+               for l in body.splitlines() if re.match(r"\s+(buffer_|global_|scratch_|s_barrier|s_waitcnt vmcnt)", l)]
+        waits = [i for i, o in enumerate(ops) if o in ("s_waitcnt 4", "s_waitcnt 8")]
+        assert waits, name
+        for i in waits:
+            n = int(ops[i].split()[1])
+            j = max(k for k in range(i) if ops[k] == "s_barrier")
+            between = [o for o in ops[j + 1:i] if not o.startswith("s_waitcnt")]
+            stores = [o for o in between if "store" in o]
+            if len(stores) != 8:
+                continue                  # another counted wait of the kernel (not the publication of half 0)
+            assert all("store" in o for o in between[:8]), (name, between)
+            assert len(between) - 8 == n and all("load" in o for o in between[8:]), (name, n, between)
+            checked += 1
+    assert checked >= 6, checked          # 1024 x 512 planar (7, 9 taps), wire format (7, 9), 2048 x 128 (7, 9)

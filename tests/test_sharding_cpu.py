@@ -44,3 +44,16 @@ def test_two_rank_gloo_run(tmp_path):
     for e in range(2):
         for s in range(7):
             assert table[e, s, 0, 0] == 100 * e + 10 * s
+
+
+def test_bench_control_plane_is_silent_and_takes_the_max():
+    """bench.py --gpus N synchronises its ranks through torch.distributed's TCP store (RankControl) -- no process group, so
+    nothing but rank 0's JSON line reaches stdout (gloo prints its connections there) -- and reports the slowest rank."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", "29643", os.path.join(ROOT, "tests", "_ctl_worker.py")],
+                       capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["world"] == 3 and d["elapsed"] >= 0.14          # rank 2's 0.15 s

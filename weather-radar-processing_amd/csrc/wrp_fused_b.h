@@ -60,6 +60,12 @@ __device__ __forceinline__ void rb_derive_twiddles(cf (&tw)[16])
 #define WRP_FUSED_B_INPUT_AUX 2   /* AUX_NT */
 #endif
 constexpr int FUSED_B_INPUT_AUX = WRP_FUSED_B_INPUT_AUX;
+// Request pacing (wrp_fused.h): 16 = one load at a time over the task, 1.69 us/sector, HBM traffic 1.13 x the algorithmic
+// bytes; 4 = four quarters, 1.74 us/sector, 1.06 x (the smoother stream leaves fewer non-temporal lines per L2 set to evict
+// in place of the slot's): profiles/r03/fused_b_input_policy.log, ab_request_pacing_B.log.
+#ifndef WRP_FUSED_B_PIECES
+#define WRP_FUSED_B_PIECES 16
+#endif
 template <int QUARTER>
 __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                   float4 (&v)[16], float2 &wdv, bool valid)
@@ -293,27 +299,44 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             const bool more = q + 1 < tasks;
             cf o[2][4];
 #define WRP_LB(R) fused_b_tile_load1<R>(next, col_base, rc.wd, v, wdv, more)
+#if WRP_FUSED_B_PIECES == 4
+            WRP_LB(0); WRP_LB(4); WRP_LB(8); WRP_LB(12);
+            fused_b_stage2(smem);
+            WRP_LB(1); WRP_LB(5); WRP_LB(9); WRP_LB(13);
+            fused_b_stage3(smem, o);
+#else
             WRP_LB(0); WRP_LB(8);
             fused_b_stage2(smem);
             WRP_LB(4); WRP_LB(12);
             fused_b_stage3(smem, o);
             WRP_LB(1); WRP_LB(9);
+#endif
             spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_b_store(mid, ch, col_base, o);
             __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
+#if WRP_FUSED_B_PIECES == 4
+            WRP_LB(2); WRP_LB(6); WRP_LB(10); WRP_LB(14);
+#else
             WRP_LB(5); WRP_LB(13); WRP_LB(2); WRP_LB(10);
+#endif
             fused_b_group1_to_lds(smem, ga, gc);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
             int last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
             if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
             __syncthreads();                    // A3: group 1 is in the image
+#if WRP_FUSED_B_PIECES == 4
+            fused_b_stage2(smem);
+            WRP_LB(3); WRP_LB(7); WRP_LB(11); WRP_LB(15);
+            fused_b_stage3(smem, o);
+#else
             WRP_LB(6);
             fused_b_stage2(smem);      // (its sixteen points + fifteen twiddles need registers: most of the rest is requested behind it)
             WRP_LB(14); WRP_LB(3);
             fused_b_stage3(smem, o);
             WRP_LB(11); WRP_LB(7); WRP_LB(15);
+#endif
 #undef WRP_LB
             spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
