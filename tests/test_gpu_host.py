@@ -178,3 +178,18 @@ def test_read_altb_is_read_cc_with_the_gpu_behind_it(tmp_path, oracle, with_ids)
     # a truncated file is refused, not misread
     r = subprocess.run([READ_ALTB], input="1 2 3\n", capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "expected a multiple" in r.stderr
+
+
+def test_rpv2_host_fill_source_and_process_entry_point():
+    """`--in synthetic:copy:T` (every sector memcpy'd from a pageable buffer into its pinned slot by T threads: the host's
+    share of an end-to-end run, bench.py's end_to_end.with_host_fill) with the GPU thread bound to its NUMA node, one and
+    two GPU threads; and `process` -- the reference's other entry-point name (Makefile:3 there) -- is the same program."""
+    import re
+    proc = os.path.join(os.path.dirname(RPV2), "process")
+    assert os.path.exists(proc) and os.path.samefile(os.path.realpath(proc), RPV2), "run `make process`"
+    for exe, devices, threads, want in ((RPV2, "0", 1, 12), (proc, "0,0", 3, 24)):
+        r = subprocess.run([exe, "2", "--devices", devices, "--in", f"synthetic:copy:{threads}", "--bind-numa", "--out", "none",
+                            "--scan", "6,2", "--sectors", "12"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"rpv2: (\d+) sectors processed .*host fill by (\d+) thread", r.stderr)
+        assert m and int(m.group(1)) == want and int(m.group(2)) == threads, r.stderr       # --sectors counts per GPU thread here
