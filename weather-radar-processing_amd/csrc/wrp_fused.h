@@ -81,6 +81,9 @@ constexpr int FUSED_STAMP_TASKS = 16;
 #ifndef WRP_FUSED_ROW_SPLIT
 #define WRP_FUSED_ROW_SPLIT 1       // 1: every row wave serves both halves, one row of each; 0: four waves per half, two rows each
 #endif
+#ifndef WRP_FUSED_ROW_PRIO
+#define WRP_FUSED_ROW_PRIO 3        // s_setprio level of a row wave between its notice of a half and its `loaded` flag (0: off)
+#endif
 #ifndef WRP_FUSED_INPUT_AUX
 #define WRP_FUSED_INPUT_AUX 2       // cache policy of the planar input loads: AUX_NT
 #endif
@@ -103,6 +106,7 @@ constexpr int FUSED_STAMP_TASKS = 16;
 #endif
 constexpr unsigned long long FUSED_JOIN_TICKS = 400000ull;   // 4 ms of s_memrealtime (100 MHz): deadline of the team meeting
 constexpr int FUSED_INPUT_AUX = WRP_FUSED_INPUT_AUX;
+constexpr int FUSED_ROW_PRIO = WRP_FUSED_ROW_PRIO;
 constexpr int FUSED_POLL_SLEEP = WRP_FUSED_POLL_SLEEP;   // s_sleep units (64 cycles) between two polls of a row wave
 constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (task 0)
 constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the gates of ONE half
@@ -1031,6 +1035,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
                 if (!there) break;                              // status is set: the launch is void
                 if (g == 0) stamp(q, 1);
+                // From the notice to the publication of `loaded` the wave runs at RAISED PRIORITY: these two dozen
+                // instructions are in the hand-over chain every tile member of the team waits for, and a row wave is the
+                // YOUNGER wave of its SIMD -- the arbiter serves the older tile waves first and leaves it the gaps.
+                // 2.32 -> 2.26 us/sector.  (Raised while polling as well: -0.5 % only, the polls then take slots from the
+                // tile waves; tile waves raised: no change; the row transform itself raised: +6 %.
+                // profiles/r03/ab_wave_priority.log: prio2 / prio3 / prio1 / prio7.)
+                __builtin_amdgcn_s_setprio(FUSED_ROW_PRIO);
                 cf x[8];
                 // (slot rows in the order the lanes read them -- pulses l + 128 k and l + 64 + 128 k side by side, four
                 // 16-byte loads per lane instead of eight 8-byte ones -- cost the tile members scattered 8-byte stores and
@@ -1040,6 +1051,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 int last = 0;
                 if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
                 if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
+                __builtin_amdgcn_s_setprio(0);
                 if (g == 0) stamp(q, 2);
 #ifdef WRP_EXP_NOROW    // timing only: the rows are loaded and handed back, not transformed
                 const float s = x[0].x + x[7].y;

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             for (int g = 0; g < 2; g++) {
                 there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
                 if (!there) break;                              // status is set: the launch is void
+                __builtin_amdgcn_s_setprio(FUSED_ROW_PRIO);     // the notice-to-`loaded` stretch at raised priority: wrp_fused.h
                 cf x[8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_SC1>(rs, voff, r * 256);
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 int last = 0;
                 if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
                 if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
+                __builtin_amdgcn_s_setprio(0);
                 const int gate = fused_b_gate(g, Q, pb);
 #ifdef WRP_EXP_B_NOROW
                 const float S = x[0].x + x[7].y;
