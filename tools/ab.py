@@ -52,7 +52,14 @@ def main():
         e = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, m=m, n=n)
         e.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
         torch.cuda.synchronize()
-        ok = bool(np.max(np.abs(d_out[1].cpu().numpy()[1:] - want[1:])) < 1e-3)
+        got = d_out.cpu().numpy()
+        ok = bool(np.max(np.abs(got[1][1:] - want[1:])) < 1e-3)
+        if not engines:
+            first = got.copy()
+        elif not args.no_check:     # the builds are meant to be bit-identical: say so, or say where they are not
+            same = np.array_equal(first.view(np.uint32), got.view(np.uint32))
+            print(f"{os.path.basename(path)}: output {'bit-identical to' if same else 'DIFFERS from'} {engines[0][0]}"
+                  + ("" if same else f" (max |diff| {np.nanmax(np.abs(first - got)):.3g})"))
         engines.append((os.path.basename(path), e, ok, []))
     k = 1e3 / (args.iters * S)
     if args.wire:

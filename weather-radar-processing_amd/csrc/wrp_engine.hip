@@ -281,7 +281,7 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
 #define WRP_FUSED_B(TAPS)                                                                                             \
     hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS>), dim3(grid), dim3(wrp::FUSED_THREADS), wrp::FusedTileB::LDS_BYTES, st, \
                        d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,           \
-                       c.k_range_resolution, c.k_calibration, h->d_status + slot)
+                       c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps)
         if (h->taps_pad == 7) WRP_FUSED_B(7); else WRP_FUSED_B(9);
 #undef WRP_FUSED_B
         HIP_TRY(h, hipGetLastError());
@@ -974,7 +974,7 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
                            unsigned long long *host_stamps, size_t host_count)
 {
     if (!h || !d_iq || !d_out || !host_stamps || n_sectors <= 0) return WRP_ERR_INVALID;
-    if (!h->tuned) return WRP_ERR_UNSUPPORTED;   // the fused launch exists for 1024 x 512 only
+    if (!h->tuned && !h->tuned_b) return WRP_ERR_UNSUPPORTED;   // (2048 x 128 stamps only in a -DWRP_EXP_B_STAMPS build: zeros otherwise)
     const size_t count = (size_t)h->n_cus * 2 * wrp::FUSED_STAMP_TASKS * wrp::FUSED_STAMPS;
     if (host_count < count) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

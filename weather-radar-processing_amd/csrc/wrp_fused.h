@@ -292,6 +292,16 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));   // recompute the lane offsets per call instead of keeping (spilling) them
     const int p0 = w * 8 + (l >> 3), cp = l & 7;
+#ifdef WRP_EXP_NOLOOK   // timing only: the tile members never wait for the rows (results may be wrong)
+#define WRP_EXP_LOOKSKIP(x) true
+#else
+#define WRP_EXP_LOOKSKIP(x) (x)
+#endif
+#ifdef WRP_EXP_NOPOLL   // timing only: the row members never wait for the tile members (results are wrong)
+#define WRP_EXP_POLLSKIP(x) true
+#else
+#define WRP_EXP_POLLSKIP(x) (x)
+#endif
 #ifdef WRP_EXP_NOLOAD   // timing only: what the launch costs without its input (results are wrong)
     valid = false;
 #endif
@@ -386,7 +396,7 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
-        a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
+        a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
     }
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
@@ -680,7 +690,7 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
     for (int r = 0; r < 16; r++) {
         const float wgt = s_wr[p0 + 64 * r] * wdv;
         const cf x = wire_sample(CH ? v[2 * r + ITEM].y : v[2 * r + ITEM].x);
-        a[r] = make_float2(x.x * wgt, x.y * wgt);
+        a[r] = cscale(x, wgt);
     }
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
@@ -946,7 +956,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             // row loads is what every tile member waited for); 1 MiB does -- write-backs 3.5 -> 0.5 MB per sector at
             // the same speed.  The look comes as late as it can: one wave, in front of the barrier behind which the
             // stores go out.
-            spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
+            spin_flags_sticky(my_loaded1, (unsigned)q, failed, WRP_EXP_LOOKSKIP(w != 0));
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_store(mid, tile_col(q), 0, o);
             // BEHIND the stores, so that a counted wait can tell them apart: the scheduling barrier keeps the four loads
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             fused_stage2(smem);
             fused_stage3(smem, o);
 #endif
-            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
+            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, WRP_EXP_LOOKSKIP(w != 0));
             stamp(q, 7);
             __syncthreads();                    // A4: image free for the next stage 1; the slot is free for half 1 (the rows have half 0 of THIS task)
             fused_store(mid, tile_col(q), 1, o);
@@ -1032,7 +1042,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             for (int g = 0; g < 2; g++) {
                 const int gate = rank * 16 + 8 * g + w;
                 if (g == 0) stamp(q, 0);
-                there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
+                there = there && WRP_EXP_POLLSKIP(spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status));
                 if (!there) break;                              // status is set: the launch is void
                 if (g == 0) stamp(q, 1);
                 // From the notice to the publication of `loaded` the wave runs at RAISED PRIORITY: these two dozen

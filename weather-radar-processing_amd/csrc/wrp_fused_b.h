@@ -33,7 +33,12 @@ struct FusedTileB {
     static constexpr int OFF_WR = IMG_BYTES;                      // float wr_c[1024]: the first half of the window
     static constexpr int OFF_CTL = OFF_WR + (RB_M / 2) * 4;       // 77824: control words, both kinds (as FusedTile)
     static constexpr int OFF_TW2 = OFF_CTL + 64;                  // float2 [16 k2][8 p1]: W_128^{p1 k2}
+#ifdef WRP_EXP_B_STAMPS   // diagnostics build (tools/fused_stamps_b.py): [16 tasks][9] 64-bit stamps behind the tables
+    static constexpr int OFF_STAMPS = OFF_TW2 + 16 * 8 * 8;
+    static constexpr int LDS_BYTES = OFF_STAMPS + FUSED_STAMP_TASKS * FUSED_STAMPS * 8;   // 80064: still two per CU
+#else
     static constexpr int LDS_BYTES = OFF_TW2 + 16 * 8 * 8;        // 78912
+#endif
     static constexpr int OFF_TWN = 8 * 4 * DB_ROW_ELEMS * 8;      // row workgroup: 8 waves x 4 row buffers, then exp(+2 pi i k / 128)
     static_assert(OFF_TWN + RB_N * 8 <= OFF_CTL, "row workgroup layout fits");
     static_assert(OFF_CTL == FusedTile::OFF_CTL, "the control words sit where fused_join / fused_leave expect them");
@@ -104,6 +109,9 @@ __device__ __forceinline__ void fused_b_tile_load1(const float2 *src /* wave-uni
 #ifdef WRP_EXP_B_NOLOAD
     valid = false;
 #endif
+#ifdef WRP_EXP_B_DROP     // timing only: the pieces of this bit mask are not fetched (zero-record descriptor)
+    if ((WRP_EXP_B_DROP >> R) & 1) valid = false;
+#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
     const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
     v[R] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8);
@@ -141,7 +149,7 @@ __device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
-        a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
+        a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
     }
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     float *__restrict__ out,         // [S][1024][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS]: per team ONE slot [2 channels][512][128] through which both halves go
     FusedCtl *ctl, RangeConsts rc /* wr_c symmetric */, const float2 *__restrict__ tw_n /* exp(+2 pi i k / 128) */, int n_sectors,
-    int channels, MaTaps taps, float k_rr, float k_cal, unsigned *host_status)
+    int channels, MaTaps taps, float k_rr, float k_cal, unsigned *host_status, unsigned long long *stamps /* -DWRP_EXP_B_STAMPS builds only */)
 {
     typedef FusedTileB T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -257,6 +265,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     }
     const int tasks = (n_sectors - trank + teams - 1) / teams;   // sectors of this team: one task each
     float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
+#ifdef WRP_EXP_B_STAMPS
+    unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(smem + T::OFF_STAMPS);
+    for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS) s_stamps[e] = 0;
+    __syncthreads();
+    if (tid == 0) s_stamps[FUSED_STAMPS - 1] = ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+    auto stamp = [&](int q, int k) {   // wave 0 of the workgroup, slots 0 .. 7 of the task
+        if (w == 0 && q < FUSED_STAMP_TASKS) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if (l == 0) s_stamps[q * FUSED_STAMPS + k] = t;
+        }
+    };
+    auto flush_stamps = [&]() {
+        if (stamps) {
+            if (tid == 0) {
+                s_stamps[1 * FUSED_STAMPS + FUSED_STAMPS - 1] = __builtin_amdgcn_s_memtime() - clk_t0;
+                s_stamps[2 * FUSED_STAMPS + FUSED_STAMPS - 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+            }
+            __syncthreads();
+            for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS)
+                stamps[(size_t)blockIdx.x * FUSED_STAMP_TASKS * FUSED_STAMPS + e] = s_stamps[e];
+        }
+    };
+#else
+    auto stamp = [](int, int) {};
+    auto flush_stamps = []() {};
+#endif
 
     if (kind == 0) {
         // =============================== tile member: channel rank >> 4, 8-column tile rank & 15 ===============================
@@ -285,8 +320,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             cf ga[8], gc[8];
             {
                 cf tw[16];
+                stamp(q, 0);
                 fused_b_stage1_tables(smem, tw);
                 fused_b_stage1<0>(smem, v, wdv, tw, ga);
+                stamp(q, 5);
                 // half 1 of the previous task was stored half a stage ago: drained and counted here (see wrp_fused.h)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int last = 0;
@@ -295,6 +332,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 fused_b_stage1<1>(smem, v, wdv, tw, gc);
             }
             __syncthreads();                    // A1: group 0 is in the image
+            stamp(q, 1);
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
             const bool more = q + 1 < tasks;
             cf o[2][4];
@@ -321,11 +359,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             WRP_LB(5); WRP_LB(13); WRP_LB(2); WRP_LB(10);
 #endif
             fused_b_group1_to_lds(smem, ga, gc);
+            stamp(q, 2);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
+            stamp(q, 6);
             int last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
             if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
             __syncthreads();                    // A3: group 1 is in the image
+            stamp(q, 3);
 #if WRP_FUSED_B_PIECES == 4
             fused_b_stage2(smem);
             WRP_LB(3); WRP_LB(7); WRP_LB(11); WRP_LB(15);
@@ -338,7 +379,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             WRP_LB(11); WRP_LB(7); WRP_LB(15);
 #endif
 #undef WRP_LB
+            stamp(q, 7);
             spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
+            stamp(q, 4);
             __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
             fused_b_store(mid, ch, col_base, o);
         }
@@ -346,6 +389,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         __syncthreads();
         if (tasks > 0 && w == 0) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)tasks);
         if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flush_stamps();
         fused_leave(ctl, host_status, xcc, s_ctl);
     } else {
         // =============================== row member ===============================
@@ -366,8 +410,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             float *o2 = &out[(size_t)(trank + q * teams) * gates * 2];
 #pragma unroll
             for (int g = 0; g < 2; g++) {
+                stamp(q, 4 * g);
                 there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
                 if (!there) break;                              // status is set: the launch is void
+                stamp(q, 4 * g + 1);
                 __builtin_amdgcn_s_setprio(FUSED_ROW_PRIO);     // the notice-to-`loaded` stretch at raised priority: wrp_fused.h
                 cf x[8];
 #pragma unroll
@@ -377,6 +423,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
                 if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
                 __builtin_amdgcn_s_setprio(0);
+                stamp(q, 4 * g + 2);
                 const int gate = fused_b_gate(g, Q, pb);
 #ifdef WRP_EXP_B_NOROW
                 const float S = x[0].x + x[7].y;
@@ -385,9 +432,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
 #endif
                 const float other = __shfl(S, (l + 32) & 63);     // the VV row sum sits 32 lanes above the HH one
                 if (i == 0 && chn == 0) reflectivity_store(o2 + 2 * gate, gate, S, other, k_rr, k_cal);
+                stamp(q, 4 * g + 3);
             }
             if (!there) break;
         }
+        flush_stamps();
         fused_leave(ctl, host_status, xcc, s_ctl);
     }
 }

@@ -194,8 +194,8 @@ __device__ __forceinline__ void range_stage12(unsigned char *smem, float4 (&v)[1
         for (int r = 0; r < 16; r++) {
             const float wrow = s_wr[p0 + 64 * r];
             const float w0 = wrow * wdv.x, w1 = wrow * wdv.y;
-            a[r] = make_float2(v[r].x * w0, v[r].y * w0);
-            c[r] = make_float2(v[r].z * w1, v[r].w * w1);
+            a[r] = cscale(make_float2(v[r].x, v[r].y), w0);
+            c[r] = cscale(make_float2(v[r].z, v[r].w), w1);
         }
         if (DUMP && do_dump && dump.hamm) {
 #pragma unroll

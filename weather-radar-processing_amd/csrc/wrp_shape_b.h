@@ -81,7 +81,7 @@ __device__ __forceinline__ void rb_stage1(unsigned char *smem, const float4 (&v)
 #pragma unroll
     for (int r = 0; r < 16; r++) {   // (a batch of the sixteen window reads costs this kernel 19 spilled registers)
         const float wgt = s_wr[p0 + 128 * r] * (COLUMN ? wdv.y : wdv.x);
-        a[r] = COLUMN ? make_float2(v[r].z * wgt, v[r].w * wgt) : make_float2(v[r].x * wgt, v[r].y * wgt);
+        a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
     }
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
