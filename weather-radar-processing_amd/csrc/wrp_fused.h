@@ -149,6 +149,17 @@ struct FusedTile {
     static_assert(OFF_TWN + DP_TW_ELEMS * 8 <= OFF_CTL, "row workgroup layout fits");
     static_assert(2 * LDS_BYTES <= 160 * 1024 && 3 * LDS_BYTES > 160 * 1024, "exactly two workgroups per CU");
     static __device__ __forceinline__ int addr(int pos, int cp) { return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + cp * 16; }
+    // The sixteen columns of a position are one 128-byte row; in the rows of ODD positions the two columns of every pair
+    // are swapped (column c sits at (c ^ (pos & 1)) * 8).  Stage 1 writes ONE column of a pair at a time, 8 bytes per lane at
+    // a 16-byte stride, and a ds_write_b64 serves sixteen lanes at once -- two rows: unswapped, both rows' 8-byte pieces
+    // fall on the same sixteen banks (two passes per write, 55 % of the launch's bank-conflict cycles); swapped, the odd
+    // row takes the other sixteen (SQ_LDS_BANK_CONFLICT 21.5 M -> 9.7 M per launch, 9.3 % -> 4.4 % of the LDS's active
+    // cycles; the launch is no faster for it: stage 1 is bound by its arithmetic).  Every other access covers whole rows and
+    // only sees its columns permuted.  The wire-format launch writes whole rows in stage 1 and keeps the plain order.
+#ifndef WRP_FUSED_SWIZZLE
+#define WRP_FUSED_SWIZZLE 1
+#endif
+    template <bool SWZ = true> static __device__ __forceinline__ int swz(int pos) { return SWZ && WRP_FUSED_SWIZZLE ? (pos & 1) : 0; }
     // Stage-1 twiddles W_1024^{p0 k1} ARRANGED in the 64 pads so that a lane reads its fifteen at ONE base + immediate
     // offsets, and the eight positions p0 = 8 w .. 8 w + 7 of a wave are 64 contiguous bytes (no bank conflict): pad
     // 8 (p0 >> 3) + (k1 >> 1), byte 64 (k1 & 1) + 8 (p0 & 7).
@@ -387,7 +398,7 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
-    const int slot = T::addr(p0, cp) + 8 * COLUMN;   // position k1*64 + p0 is 8 k1 blocks further on
+    const int slot = T::addr(p0, cp) + 8 * (COLUMN ^ T::swz(p0));   // position k1*64 + p0 is 8 k1 blocks further on (same parity)
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
     float wr[16];    // one batch of eight reads (the window of the column's sixteen rows), one wait
 #pragma unroll
@@ -415,9 +426,18 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
+#if WRP_FUSED_SWIZZLE
+    const int first = T::addr(p0, cp) + 8 * T::swz(p0), second = T::addr(p0, cp) + 8 * (1 ^ T::swz(p0));   // two conflict-free b64 = one b128 in LDS cycles
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        *reinterpret_cast<float2 *>(smem + first + j * 8 * T::BLK_BYTES) = ga[j];
+        *reinterpret_cast<float2 *>(smem + second + j * 8 * T::BLK_BYTES) = gc[j];
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 8; j++)
         *reinterpret_cast<float4 *>(smem + T::addr(j * 64 + p0, cp)) = make_float4(ga[j].x, ga[j].y, gc[j].x, gc[j].y);
+#endif
 }
 
 // stages 2 and 3 of the sub-transform this WAVE owns in the current group (image rows w*64 ..) and
@@ -431,7 +451,7 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
 // L2, where the row members find them; 16 lanes x 8 bytes = one whole 128-byte line per gate.
 // stages 2 and 3 are written per ITEM (two per lane and stage) so that the launch can place a request for the next tile
 // between any two of them
-template <int IT>
+template <int IT, bool SWZ = true>
 __device__ __forceinline__ void fused_stage2_item(unsigned char *smem)
 {
     typedef FusedTile T;
@@ -439,9 +459,9 @@ __device__ __forceinline__ void fused_stage2_item(unsigned char *smem)
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
-    unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;   // position w*64 of this lane's column
-    // stage 2: radix 8 over positions p1 + 8 r, twiddle W_64^{p1 k2}, in place
+    // stage 2: radix 8 over positions p1 + 8 r (all of p1's parity), twiddle W_64^{p1 k2}, in place
     const int p1 = (l >> 4) + 4 * IT;
+    unsigned char *base = smem + w * 8 * T::BLK_BYTES + (col ^ T::swz<SWZ>(p1)) * 8;   // position w*64 of this lane's column
     cf a[8], t[8];   // the seven twiddles in one batch with the data, not one LDS round trip each
 #pragma unroll
     for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES + p1 * T::ROW_BYTES);
@@ -460,7 +480,7 @@ __device__ __forceinline__ void fused_stage2(unsigned char *smem)
     fused_stage2_item<0>(smem);
     fused_stage2_item<1>(smem);
 }
-template <int IT>
+template <int IT, bool SWZ = true>
 __device__ __forceinline__ void fused_stage3_item(unsigned char *smem, cf (&o)[2][4])
 {
     typedef FusedTile T;
@@ -468,11 +488,11 @@ __device__ __forceinline__ void fused_stage3_item(unsigned char *smem, cf (&o)[2
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 15;
-    unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8;
+    unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8, *base_odd = smem + w * 8 * T::BLK_BYTES + (col ^ T::swz<SWZ>(1)) * 8;
     const int k2 = (l >> 4) + 4 * IT;     // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
     cf a[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
+    for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>((r & 1 ? base_odd : base) + k2 * T::BLK_BYTES + r * T::ROW_BYTES);
     fft8<-1>(a);
 #pragma unroll
     for (int k3 = 0; k3 < 4; k3++) o[IT][k3] = a[k3];
@@ -764,13 +784,13 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         cf o[2][4];
 #define WRP_LR(RR) if (CH) fused_raw_tile_load1<RR>(next, next_col, rc.wd, v, wdv, more)
         WRP_LR(0); WRP_LR(8);
-        fused_stage2_item<0>(smem);
+        fused_stage2_item<0, false>(smem);
         WRP_LR(4);
-        fused_stage2_item<1>(smem);
+        fused_stage2_item<1, false>(smem);
         WRP_LR(12);
-        fused_stage3_item<0>(smem, o);
+        fused_stage3_item<0, false>(smem, o);
         WRP_LR(1);
-        fused_stage3_item<1>(smem, o);
+        fused_stage3_item<1, false>(smem, o);
         WRP_LR(9);
         spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
         __syncthreads();                    // A2
@@ -785,13 +805,13 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
         __syncthreads();                    // A3
         WRP_LR(6);
-        fused_stage2_item<0>(smem);
+        fused_stage2_item<0, false>(smem);
         WRP_LR(14);
-        fused_stage2_item<1>(smem);
+        fused_stage2_item<1, false>(smem);
         WRP_LR(3);
-        fused_stage3_item<0>(smem, o);
+        fused_stage3_item<0, false>(smem, o);
         WRP_LR(11);
-        fused_stage3_item<1>(smem, o);
+        fused_stage3_item<1, false>(smem, o);
         WRP_LR(7); WRP_LR(15);
 #undef WRP_LR
         spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
