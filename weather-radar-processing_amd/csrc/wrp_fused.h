@@ -101,6 +101,14 @@ constexpr int FUSED_STAMP_TASKS = 16;
 #ifndef WRP_FUSED_CU_KINDS
 #define WRP_FUSED_CU_KINDS 0        // 1: tile CUs and row CUs (two workgroups of ONE kind per CU); 0: a tile and a row workgroup on every CU
 #endif
+#ifndef WRP_FUSED_UNIFORM_W
+#define WRP_FUSED_UNIFORM_W 1
+#endif
+#if WRP_FUSED_UNIFORM_W    // the wave's index as a scalar: its share of the LDS addresses is scalar arithmetic
+#define WRP_W(tid) wave_id()
+#else
+#define WRP_W(tid) ((tid) >> 6)
+#endif
 #ifndef WRP_FUSED_ROW_POLLERS
 #define WRP_FUSED_ROW_POLLERS 0     // 1: one wave per half polls the L2 and wakes the other three (measured slower: above)
 #endif
@@ -375,7 +383,7 @@ __device__ __forceinline__ void fused_stage1_tables(const unsigned char *smem, F
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // per-lane LDS addresses are recomputed per tile, not hoisted + spilled
     tid &= FUSED_THREADS - 1;       // (the compiler knows the range again: address arithmetic folds)
-    const int w = tid >> 6, l = tid & 63;
+    const int w = WRP_W(tid), l = tid & 63;
     const int p0 = w * 8 + (l >> 3);
     const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);   // k1 further on: a compile-time offset
 #pragma unroll
@@ -396,7 +404,7 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, cp = l & 7;
+    const int w = WRP_W(tid), l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
     const int slot = T::addr(p0, cp) + 8 * (COLUMN ^ T::swz(p0));   // position k1*64 + p0 is 8 k1 blocks further on (same parity)
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
@@ -424,7 +432,7 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, cp = l & 7;
+    const int w = WRP_W(tid), l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
 #if WRP_FUSED_SWIZZLE
     const int first = T::addr(p0, cp) + 8 * T::swz(p0), second = T::addr(p0, cp) + 8 * (1 ^ T::swz(p0));   // two conflict-free b64 = one b128 in LDS cycles
@@ -458,7 +466,7 @@ __device__ __forceinline__ void fused_stage2_item(unsigned char *smem)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    const int w = WRP_W(tid), l = tid & 63, col = l & 15;
     // stage 2: radix 8 over positions p1 + 8 r (all of p1's parity), twiddle W_64^{p1 k2}, in place
     const int p1 = (l >> 4) + 4 * IT;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + (col ^ T::swz<SWZ>(p1)) * 8;   // position w*64 of this lane's column
@@ -487,7 +495,7 @@ __device__ __forceinline__ void fused_stage3_item(unsigned char *smem, cf (&o)[2
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    const int w = WRP_W(tid), l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8, *base_odd = smem + w * 8 * T::BLK_BYTES + (col ^ T::swz<SWZ>(1)) * 8;
     const int k2 = (l >> 4) + 4 * IT;     // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
     cf a[8];
@@ -507,7 +515,7 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, col = l & 15;
+    const int w = WRP_W(tid), l = tid & 63, col = l & 15;
     const rsrc_t rd = make_rsrc(mid, (unsigned)FUSED_SLOT_ROWS * DP_N * 8u);
     // slot row of gate k1 + 16 k2 + 128 k3 (k1 = w + 8 group, k2 = (l >> 4) + 4 it): (gate >> 4) * 8 + (gate & 7)
     const int voff = ((w + 8 * (l >> 4)) * DP_N + col_base + col) * 8;
@@ -700,7 +708,7 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, c = l & 15;
+    const int w = WRP_W(tid), l = tid & 63, c = l & 15;
     const int p0 = w * 4 + (l >> 4) + 32 * ITEM;
     const int slot = T::addr(p0, c >> 1) + 8 * (c & 1);
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
@@ -730,7 +738,7 @@ __device__ __forceinline__ void fused_raw_group1_to_lds(unsigned char *smem, con
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = tid >> 6, l = tid & 63, c = l & 15;
+    const int w = WRP_W(tid), l = tid & 63, c = l & 15;
     const int pq = w * 4 + (l >> 4);
     const int slot = T::addr(pq, c >> 1) + 8 * (c & 1);
 #pragma unroll
