@@ -142,14 +142,42 @@ __device__ __forceinline__ void fft8(cf (&v)[8])
     }
 }
 
+// the first level of fft16 on inputs that still want their real weights: x_i = w_i a_i.  w0 a0 +- w2 a2 is one product and
+// two fused multiply-adds per component instead of two products, an add and a subtract: 20 instructions instead of 24
+template <int SIGN>
+__device__ __forceinline__ void fft4_scaled(cf &x0, cf &x1, cf &x2, cf &x3, float w0, float w1, float w2, float w3)
+{
+    const v2f s2 = pk(x2) * (v2f){w2, w2}, s3 = pk(x3) * (v2f){w3, w3};
+    const cf t0 = unpk(__builtin_elementwise_fma(pk(x0), (v2f){w0, w0}, s2)), t1 = unpk(__builtin_elementwise_fma(pk(x0), (v2f){w0, w0}, -s2));
+    const cf t2 = unpk(__builtin_elementwise_fma(pk(x1), (v2f){w1, w1}, s3)), d = unpk(__builtin_elementwise_fma(pk(x1), (v2f){w1, w1}, -s3));
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = cadd_rot<SIGN>(t1, d);
+    x3 = csub_rot<SIGN>(t1, d);
+}
+template <int SIGN> __device__ __forceinline__ void fft16_tail(cf (&v)[16]);
 template <int SIGN>
 __device__ __forceinline__ void fft16(cf (&v)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) fft4<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12]);
+    fft16_tail<SIGN>(v);
+}
+// fft16 of (w[r] s) * v[r] (the window of the range stage: row weight x column weight): the weights ride on the first
+// level, each product w[r] s formed where it is used
+template <int SIGN>
+__device__ __forceinline__ void fft16_scaled(cf (&v)[16], const float (&w)[16], float s)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) fft4_scaled<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12], w[r] * s, w[r + 4] * s, w[r + 8] * s, w[r + 12] * s);
+    fft16_tail<SIGN>(v);
+}
+template <int SIGN>
+__device__ __forceinline__ void fft16_tail(cf (&v)[16])
 {
     constexpr float c1 = 0.92387953251128675613f; // cos(pi/8)
     constexpr float s1 = 0.38268343236508977173f; // sin(pi/8)
     constexpr float sg = (float)SIGN;
-#pragma unroll
-    for (int r = 0; r < 4; r++) fft4<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12]);
     v[5] = cmul_const(v[5], make_float2(c1, sg * s1));
     v[6] = mul_w8_1<SIGN>(v[6]);
     v[7] = cmul_const(v[7], make_float2(s1, sg * c1));
@@ -253,14 +281,43 @@ __device__ __forceinline__ void fft8(cf (&v)[8])
 
 // 16-point as 4 x 4: F_r = fft4(x[r], x[r+4], x[r+8], x[r+12]);
 // X[k' + 4k''] = fft4 over r of (W16^{r k'} F_r[k'])
+// the first level of fft16 on inputs that still want their real weights: x_i = w_i a_i.  w0 a0 +- w2 a2 is one product and
+// two fused multiply-adds per component instead of two products, an add and a subtract: 20 instructions instead of 24
+template <int SIGN>
+__device__ __forceinline__ void fft4_scaled(cf &x0, cf &x1, cf &x2, cf &x3, float w0, float w1, float w2, float w3)
+{
+    const cf s2 = cscale(x2, w2), s3 = cscale(x3, w3);
+    const cf t0 = make_float2(fmaf(x0.x, w0, s2.x), fmaf(x0.y, w0, s2.y)), t1 = make_float2(fmaf(x0.x, w0, -s2.x), fmaf(x0.y, w0, -s2.y));
+    const cf t2 = make_float2(fmaf(x1.x, w1, s3.x), fmaf(x1.y, w1, s3.y));
+    const cf t3 = mul_si<SIGN>(make_float2(fmaf(x1.x, w1, -s3.x), fmaf(x1.y, w1, -s3.y)));
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = cadd(t1, t3);
+    x3 = csub(t1, t3);
+}
+template <int SIGN> __device__ __forceinline__ void fft16_tail(cf (&v)[16]);
 template <int SIGN>
 __device__ __forceinline__ void fft16(cf (&v)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) fft4<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12]);
+    fft16_tail<SIGN>(v);
+}
+// fft16 of (w[r] s) * v[r] (the window of the range stage: row weight x column weight): the weights ride on the first
+// level, each product w[r] s formed where it is used
+template <int SIGN>
+__device__ __forceinline__ void fft16_scaled(cf (&v)[16], const float (&w)[16], float s)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) fft4_scaled<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12], w[r] * s, w[r + 4] * s, w[r + 8] * s, w[r + 12] * s);
+    fft16_tail<SIGN>(v);
+}
+template <int SIGN>
+__device__ __forceinline__ void fft16_tail(cf (&v)[16])
 {
     constexpr float c1 = 0.92387953251128675613f; // cos(pi/8)
     constexpr float s1 = 0.38268343236508977173f; // sin(pi/8)
     constexpr float sg = (float)SIGN;
-#pragma unroll
-    for (int r = 0; r < 4; r++) fft4<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12]);
     // now v[r + 4k'] = F_r[k'].  Apply W16^{r k'}:
     // k' = 1: r=1 -> W16^1, r=2 -> W16^2 = W8^1, r=3 -> W16^3
     v[5] = cmul(v[5], make_float2(c1, sg * s1));

@@ -413,11 +413,8 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     for (int r = 0; r < 16; r++) wr[r] = s_wr[p0 + 64 * r];
     cf a[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
-        a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
-    }
-    fft16<-1>(a);
+    for (int r = 0; r < 16; r++) a[r] = COLUMN ? make_float2(v[r].z, v[r].w) : make_float2(v[r].x, v[r].y);
+    fft16_scaled<-1>(a, wr, COLUMN ? wdv.y : wdv.x);        // the window rides on the first butterflies (fft_radix.h)
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) *reinterpret_cast<float2 *>(smem + slot + k1 * 8 * T::BLK_BYTES) = cmul(a[k1], t.tw[k1]);
@@ -714,13 +711,13 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
     const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);
     cf a[16];
+    float wgt[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float wgt = s_wr[p0 + 64 * r] * wdv;
-        const cf x = wire_sample(CH ? v[2 * r + ITEM].y : v[2 * r + ITEM].x);
-        a[r] = cscale(x, wgt);
+        wgt[r] = s_wr[p0 + 64 * r];
+        a[r] = wire_sample(CH ? v[2 * r + ITEM].y : v[2 * r + ITEM].x);
     }
-    fft16<-1>(a);
+    fft16_scaled<-1>(a, wgt, wdv);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
     cf t[8];
 #pragma unroll

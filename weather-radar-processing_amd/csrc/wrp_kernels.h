@@ -190,25 +190,26 @@ __device__ __forceinline__ void range_stage12(unsigned char *smem, float4 (&v)[1
         const int col0 = col_base + cp * 2;
         const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
         cf a[16], c[16];
+        float wrow[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float wrow = s_wr[p0 + 64 * r];
-            const float w0 = wrow * wdv.x, w1 = wrow * wdv.y;
-            a[r] = cscale(make_float2(v[r].x, v[r].y), w0);
-            c[r] = cscale(make_float2(v[r].z, v[r].w), w1);
+            wrow[r] = s_wr[p0 + 64 * r];
+            a[r] = make_float2(v[r].x, v[r].y);
+            c[r] = make_float2(v[r].z, v[r].w);
         }
-        if (DUMP && do_dump && dump.hamm) {
+        if (DUMP && do_dump && dump.hamm) {   // a2 as a stage of its own: the production form folds it into the butterflies below
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                *reinterpret_cast<float4 *>(&dump.hamm[(size_t)(p0 + 64 * r) * n + col0]) =
-                    make_float4(a[r].x, a[r].y, c[r].x, c[r].y);
+            for (int r = 0; r < 16; r++) {
+                const cf ha = cscale(a[r], wrow[r] * wdv.x), hc = cscale(c[r], wrow[r] * wdv.y);
+                *reinterpret_cast<float4 *>(&dump.hamm[(size_t)(p0 + 64 * r) * n + col0]) = make_float4(ha.x, ha.y, hc.x, hc.y);
+            }
         }
         cf tw1[16];   // all 15 twiddles requested in one batch, ahead of the butterflies (one LDS latency)
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++)
             tw1[k1] = *reinterpret_cast<const float2 *>(smem + T::tw_addr((p0 * k1) & (RP_M - 1)));
-        fft16<-1>(a);
-        fft16<-1>(c);
+        fft16_scaled<-1>(a, wrow, wdv.x);
+        fft16_scaled<-1>(c, wrow, wdv.y);
         *reinterpret_cast<float4 *>(smem + T::addr(p0, cp)) = make_float4(a[0].x, a[0].y, c[0].x, c[0].y);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++) {
