@@ -526,7 +526,7 @@ int create_impl(wrp_engine *h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES));
     HIP_TRY(h, hipEventCreateWithFlags(&h->lane.done, hipEventDisableTiming));
     HIP_TRY(h, hipMalloc(&h->lane.d_ctl, sizeof(wrp::FusedCtl)));
-    HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
+    HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS * WRP_FUSED_B_SLOTS));   // (x 2 in the two-slot experiment of wrp_fused_b.h)
     for (auto &e : h->ev_ring) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * WRP_RING, hipHostMallocMapped));
     std::memset(h->h_status, 0, sizeof(unsigned) * WRP_RING);

@@ -68,6 +68,9 @@ constexpr int FUSED_B_INPUT_AUX = WRP_FUSED_B_INPUT_AUX;
 // Request pacing (wrp_fused.h): 16 = one load at a time over the task, 1.69 us/sector, HBM traffic 1.13 x the algorithmic
 // bytes; 4 = four quarters, 1.74 us/sector, 1.06 x (the smoother stream leaves fewer non-temporal lines per L2 set to evict
 // in place of the slot's): profiles/r03/fused_b_input_policy.log, ab_request_pacing_B.log.
+#ifndef WRP_FUSED_B_SLOTS
+#define WRP_FUSED_B_SLOTS 1     // 2: one slot per half (A/B: no wait for `loaded` inside a task; 2 MiB per XCD do not stay in the L2)
+#endif
 #ifndef WRP_FUSED_B_PIECES
 #define WRP_FUSED_B_PIECES 16
 #endif
@@ -114,7 +117,11 @@ __device__ __forceinline__ void fused_b_tile_load1(const float2 *src /* wave-uni
 #endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
     const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
+#ifdef WRP_EXP_B_HALFBYTES   // timing only: the same sixteen requests per wave, HALF the bytes each (results are wrong)
+    { const float2 h = buf_load_f2<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8); v[R] = make_float4(h.x, h.y, h.x, h.y); }
+#else
     v[R] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8);
+#endif
     if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         return;
     }
     const int tasks = (n_sectors - trank + teams - 1) / teams;   // sectors of this team: one task each
-    float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
+    float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS * WRP_FUSED_B_SLOTS;
+    float2 *mid1 = mid + (WRP_FUSED_B_SLOTS - 1) * FUSED_TEAM_ELEMS;     // where half 1 goes
 #ifdef WRP_EXP_B_STAMPS
     unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(smem + T::OFF_STAMPS);
     for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS) s_stamps[e] = 0;
@@ -296,7 +304,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     if (kind == 0) {
         // =============================== tile member: channel rank >> 4, 8-column tile rank & 15 ===============================
         const int ch = rank >> 4, col_base = (rank & 15) * 8;
+#ifdef WRP_EXP_B_SAMESECTOR   // timing only: every task reads the team's FIRST sector again (Infinity Cache / L2 hits, real data)
+        auto tile_src = [&](int q) { return iq + ((size_t)(trank + 0 * q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
+#else
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
+#endif
         float4 v[16];
         float2 wdv;
         fused_b_tile_load<0>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             fused_b_stage3(smem, o);
             WRP_LB(1); WRP_LB(9);
 #endif
-            spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1
+            spin_flags_sticky(WRP_FUSED_B_SLOTS == 2 ? my_loaded0 : my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1 (two slots: half 0 of task q - 1)
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_b_store(mid, ch, col_base, o);
             __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
@@ -380,10 +392,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
 #endif
 #undef WRP_LB
             stamp(q, 7);
-            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
+            spin_flags_sticky(WRP_FUSED_B_SLOTS == 2 ? my_loaded1 : my_loaded0, (unsigned)(WRP_FUSED_B_SLOTS == 2 ? q : q + 1), failed, w != 0);
             stamp(q, 4);
             __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
-            fused_b_store(mid, ch, col_base, o);
+            fused_b_store(mid1, ch, col_base, o);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         __syncthreads();
         const int sub = l >> 4, i = l & 15, pb = sub & 1, chn = sub >> 1;
         float2 *rbuf = reinterpret_cast<float2 *>(smem) + (size_t)(w * 4 + sub) * DB_ROW_ELEMS;
-        const rsrc_t rs = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
+        const rsrc_t rs0 = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u), rs1 = make_rsrc(mid1, (unsigned)FUSED_TEAM_ELEMS * 8u);
         const int Q = 8 * rank + w;
         const int voff = (chn * 256 + Q) * 2048 + (i >> 3) * 128 + pb * 64 + (i & 7) * 8;   // element j = i + 16 r: tile 2 r + (i >> 3)
 #pragma unroll 1
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 __builtin_amdgcn_s_setprio(FUSED_ROW_PRIO);     // the notice-to-`loaded` stretch at raised priority: wrp_fused.h
                 cf x[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_SC1>(rs, voff, r * 256);
+                for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_SC1>(g ? rs1 : rs0, voff, r * 256);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
                 int last = 0;
                 if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
