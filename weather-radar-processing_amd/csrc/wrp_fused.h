@@ -109,6 +109,9 @@ constexpr int FUSED_STAMP_TASKS = 16;
 #else
 #define WRP_W(tid) ((tid) >> 6)
 #endif
+#ifndef WRP_FUSED_ROW_KEEP_TW
+#define WRP_FUSED_ROW_KEEP_TW 1
+#endif
 #ifndef WRP_FUSED_ROW_POLLERS
 #define WRP_FUSED_ROW_POLLERS 0     // 1: one wave per half polls the L2 and wakes the other three (measured slower: above)
 #endif
@@ -1053,6 +1056,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         doppler_twiddles_to_lds(s_twn, tw_n, tid, FUSED_THREADS);
         if (tid < 4) s_ctl[12 + tid] = 0;   // 12, 13: arrival counts of the halves; 14, 15: (poller form) tasks seen published, per half
         __syncthreads();
+        DopplerTwiddles row_tw;     // the lane's fourteen twiddles stay in registers for all of the wave's rows (wrp_kernels.h)
+        if (WRP_FUSED_ROW_KEEP_TW) doppler_row_twiddles(s_twn, l, row_tw);
         const DumpPtrs nodump{};
 #if WRP_FUSED_ROW_SPLIT
         // Every wave serves BOTH halves, one row of each: a half is then loaded by eight waves with 8 requests each instead
@@ -1091,7 +1096,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
 #ifdef WRP_EXP_NOROW    // timing only: the rows are loaded and handed back, not transformed
                 const float s = x[0].x + x[7].y;
 #else
-                const float s = doppler_row<false, TAPS>(x, wbuf, s_twn, taps, l, gate, false, nodump);
+                const float s = doppler_row<false, TAPS, WRP_FUSED_ROW_KEEP_TW != 0>(x, wbuf, s_twn, taps, l, gate, false, nodump, row_tw);
 #endif
                 if (g == 0) stamp(q, 3);
                 if ((q & 1) == 0) s_hh[g] = s;
@@ -1130,8 +1135,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
             if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
             stamp(q, 2);
-            const float s0 = doppler_row<false, TAPS>(x0, wbuf, s_twn, taps, l, g0, false, nodump);
-            const float s1 = doppler_row<false, TAPS>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump);
+            const float s0 = doppler_row<false, TAPS, WRP_FUSED_ROW_KEEP_TW != 0>(x0, wbuf, s_twn, taps, l, g0, false, nodump, row_tw);
+            const float s1 = doppler_row<false, TAPS, WRP_FUSED_ROW_KEEP_TW != 0>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump, row_tw);
             stamp(q, 3);
             if ((q & 1) == 0) {
                 s_hh0 = s0;

@@ -374,9 +374,15 @@ constexpr int DP_N = 512;
 constexpr int DP_WAVES = 4;
 constexpr int DP_ELEMS = DP_N + DP_N / 8;   // padded complex elements per wave buffer (576 = 4608 B)
 
-// element index of position p: two elements of padding per 16 (tools/lds_banks.py: stage-2/3
-// reads and stage-2 writes conflict free, stage-1 writes 1.5x -- the best of the searched maps)
-__device__ __forceinline__ int dp_idx(int pos) { return pos + 2 * (pos >> 4); }
+// element index of position p: two elements of padding per 16 (tools/lds_banks.py: stage 1's and stage 2's accesses
+// conflict free, stage 3's reads two passes: 112 LDS cycles per row for the three exchanges; with neighbours swapped
+// where bit 3 of the position is set -- WRP_DP_SWIZZLE -- 96, the ideal)
+#ifndef WRP_DP_SWIZZLE
+#define WRP_DP_SWIZZLE 0    // 1: neighbouring elements swapped where bit 3 of the position is set: stage-3 reads conflict-free too
+                            // (SQ_LDS_BANK_CONFLICT 9.7 M -> 3.8 M per launch), eight 8-byte reads instead of four 16-byte ones and a
+                            // second address register: bit-identical, +0.2 % -- not adopted (profiles/r03/ab_doppler_lds_swizzle.log)
+#endif
+__device__ __forceinline__ int dp_idx(int pos) { return (WRP_DP_SWIZZLE ? pos ^ ((pos >> 3) & 1) : pos) + 2 * (pos >> 4); }
 // float index of |.|^2 bin j: 4 floats of padding per 8 -> b32 writes and b128 reads conflict free
 __device__ __forceinline__ int dp_fidx(int j) { return j + 4 * (j >> 3); }
 
@@ -442,9 +448,22 @@ __device__ __forceinline__ void doppler_twiddles_to_lds(float2 *s_tw, const floa
 
 // a4..a8 for one row held in v (lane l: j = l + 64 r); returns S (the same value in every lane).
 // tw: the arranged LDS table of doppler_twiddles_to_lds.
-template <bool DUMP, int TAPS>
+// The lane's fourteen twiddles of a row (seven per stage): the same for every row a wave transforms.  The two-kernel
+// pass reads them per row (a wave transforms two); the row waves of the fused launch keep them in registers for their 180
+// rows -- 14 of a row's 47 LDS instructions and 7 of its 23 KiB of LDS traffic (the row role has the registers: the
+// kernel's allocation is the tile role's).
+struct DopplerTwiddles { cf t1[8], t2[8]; };
+__device__ __forceinline__ void doppler_row_twiddles(const float2 *tw, int l, DopplerTwiddles &t)
+{
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        t.t1[k] = tw[k * 64 + l];
+        t.t2[k] = tw[512 + k * 8 + (l & 7)];
+    }
+}
+template <bool DUMP, int TAPS, bool KEPT = false>
 __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const float2 *tw, const MaTaps &taps, int l,
-                                             int gate, bool do_dump, const DumpPtrs &dump)
+                                             int gate, bool do_dump, const DumpPtrs &dump, const DopplerTwiddles &kept = DopplerTwiddles{})
 {
     float *fbuf = reinterpret_cast<float *>(buf);
     asm volatile("" : "+v"(l));   // keep the per-lane LDS addresses inside the row (see range_stage12)
@@ -459,18 +478,20 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
     for (int r = 0; r < 8; r++) { v[r].x -= sr; v[r].y -= si; }
 
     // a5: Z[k] = sum_j (x_j - mu) exp(+2 pi i j k / n)   (= conj . FFT . conj)
-    cf t1[8], t2[8];                               // both twiddle sets in one batch of LDS reads
+    cf t1[8], t2[8];                               // both twiddle sets in one batch of LDS reads, or the kept ones
 #pragma unroll
     for (int k = 1; k < 8; k++) {
-        t1[k] = tw[k * 64 + l];
-        t2[k] = tw[512 + k * 8 + (l & 7)];
+        t1[k] = KEPT ? kept.t1[k] : tw[k * 64 + l];
+        t2[k] = KEPT ? kept.t2[k] : tw[512 + k * 8 + (l & 7)];
     }
     // LDS positions below are written as `lane base + compile-time offset`: with l < 64, p1, k2 < 8 the padded index
     // dp_idx(pos) = pos + 2 (pos >> 4) is linear in the unrolled counter (one address register per stage, immediates
     // for the eight elements), which the compiler does not find by itself:
     //   dp_idx(k1 64 + l)            = dp_idx(l) + 72 k1
-    //   dp_idx(k1 64 + p1 + 8 r)     = 72 k1 + p1 + 8 r + 2 (r >> 1)
-    //   dp_idx(k1 64 + 8 k2 + r)     = 72 k1 + 8 k2 + 2 (k2 >> 1) + r
+    //   dp_idx(k1 64 + p1 + 8 r)     = 72 k1 + (p1 ^ (r & 1)) + 8 r + 2 (r >> 1)
+    //   dp_idx(k1 64 + 8 k2 + r)     = 72 k1 + 8 k2 + 2 (k2 >> 1) + (r ^ (k2 & 1))
+    // (the terms in p1 ^ .. and r ^ .. only with WRP_DP_SWIZZLE: a second address register in stages 2 and 3, for the even and
+    // the odd elements of the unrolled counter)
     fft8<+1>(v);                                   // stage 1: lane l owns j = l + 64 r
     const int b1 = dp_idx(l);
     buf[b1] = v[0];
@@ -478,21 +499,22 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
     for (int k1 = 1; k1 < 8; k1++) buf[b1 + 72 * k1] = cmul(v[k1], t1[k1]);
     wave_lds_fence();
     {                                              // stage 2: lane = p1 + 8 k1, positions k1*64 + p1 + 8 r
-        const int b2 = 72 * (l >> 3) + (l & 7);
+        const int b2 = 72 * (l >> 3) + (l & 7), b2o = 72 * (l >> 3) + ((l & 7) ^ (WRP_DP_SWIZZLE ? 1 : 0));   // even / odd r
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = buf[b2 + 8 * r + 2 * (r >> 1)];
+        for (int r = 0; r < 8; r++) v[r] = buf[(r & 1 ? b2o : b2) + 8 * r + 2 * (r >> 1)];
         fft8<+1>(v);
         buf[b2] = v[0];
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) buf[b2 + 8 * k2 + 2 * (k2 >> 1)] = cmul(v[k2], t2[k2]);
+        for (int k2 = 1; k2 < 8; k2++) buf[(k2 & 1 ? b2o : b2) + 8 * k2 + 2 * (k2 >> 1)] = cmul(v[k2], t2[k2]);
     }
     wave_lds_fence();
     // stage 3: lane = k2 + 8 k1 owns positions k1*64 + k2*8 + r; output k = k1 + 8 k2 + 64 k3
     const int k2 = l & 7, k1 = l >> 3;
     const int klo = k1 + 8 * k2;
     const int b3 = 72 * k1 + 8 * k2 + 2 * (k2 >> 1);
+    const int b3e = b3 + (WRP_DP_SWIZZLE ? k2 & 1 : 0), b3o = b3 - (WRP_DP_SWIZZLE ? k2 & 1 : 0);   // element r sits at r ^ (k2 & 1)
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = buf[b3 + r];
+    for (int r = 0; r < 8; r++) v[r] = buf[(r & 1 ? b3o : b3e) + r];
     fft8<+1>(v);
     wave_lds_fence();   // everyone has read before the buffer is reused for |.|^2
 
