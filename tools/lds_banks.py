@@ -76,17 +76,25 @@ if __name__ == "__main__":
         print(f"{name:40s} total {tot:4d}  " + "  ".join(f"{n}={c}/{i}" for n, c, i in out))
         return tot
 
-    report("p + p>>3 (current), s3 lane=k2+8k1", lambda p: p + (p >> 3), False)
-    report("p + p>>3, s3 natural", lambda p: p + (p >> 3), True)
-    best = []
-    for a in range(0, 5):
-        for b in range(0, 9):
-            for c in range(0, 5):
-                idx = lambda p, a=a, b=b, c=c: p + (p >> 3) * a + (p >> 6) * b + ((p >> 3) & 7) * 0 + (p & 7) * 0 + c * 0
-                for nat in (False, True):
-                    import io, contextlib
-                    with contextlib.redirect_stdout(io.StringIO()):
-                        t = report("", idx, nat)
-                    best.append((t, a, b, nat))
-    best = sorted(set(best))[:10]
-    print(best)
+    print("Doppler row buffer, 8-byte elements (csrc/wrp_kernels.h: dp_idx); cycles / ideal per row and exchange")
+    report("p + 2 (p>>4)  (dp_idx, built)", lambda p: p + 2 * (p >> 4), False)
+    report("(p ^ bit3->bit0) + 2 (p>>4)  (WRP_DP_SWIZZLE)", lambda p: (p ^ ((p >> 3) & 1)) + 2 * (p >> 4), False)
+    report("p + p>>3  (round 1)", lambda p: p + (p >> 3), False)
+
+    # the fused launch's tile image (csrc/wrp_fused.h: FusedTile): [8 k1][64 positions][16 columns x 8 bytes], 128-byte
+    # rows, one row of padding per 8; with swz the two columns of a pair are swapped in the rows of odd positions
+    BLK = 9 * 128
+    def addr(pos, cp):
+        return (pos >> 3) * BLK + (pos & 7) * 128 + cp * 16
+    print("fused tile image (FusedTile), one wave instruction, cycles (ideal)")
+    for swz in (0, 1):
+        name = "columns of a pair swapped in odd rows" if swz else "plain"
+        s1 = [cycles("ds_write_b64", [addr(l >> 3, l & 7) + 8 * (c ^ (swz & (l >> 3) & 1)) for l in range(64)]) for c in (0, 1)]
+        if swz:
+            g1 = [cycles("ds_write_b64", [addr(l >> 3, l & 7) + 8 * (h ^ ((l >> 3) & 1)) for l in range(64)]) for h in (0, 1)]
+            g1 = f"{g1[0]} + {g1[1]} (two ds_write_b64, ideal 4 + 4)"
+        else:
+            g1 = f"{cycles('ds_write_b128', [addr(l >> 3, l & 7) for l in range(64)])} (one ds_write_b128, ideal 8)"
+        s23 = cycles("ds_read_b64", [addr(l >> 4, 0) + (((l & 15) ^ (swz & (l >> 4) & 1)) * 8) for l in range(64)])
+        print(f"  {name:40s} stage-1 write, column 0 / 1: {s1[0]} / {s1[1]} (ideal 4)   group 1 into the image: {g1}   "
+              f"stage-2/3 access: {s23} (ideal 2)")
