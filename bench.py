@@ -11,13 +11,15 @@ Infinity Cache), so re-reads cannot be served on-die.
 
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; sectors are
 sharded by rank with NO data-path collective (weak scaling: every GPU owns a full sweep);
-torch.distributed (gloo: control plane only) provides the barrier and the MAX over ranks of the
-elapsed time.
+the barrier and the MAX over ranks of the elapsed time go through torch.distributed's TCP store
+(control plane only: no process group, no RCCL).
 
 Prints ONE JSON line on rank 0 (DESIGN.md 6 defines the fields):
   value        device-resident sectors/s (PCIe not included) -- BASELINE.json's kernel-only figure
   roofline     of the dominant launch, from HIP events on the engine's own stream in this run;
                `traffic` from the rocprofv3 PMC run of the SAME library sources (fingerprint checked)
+  wire_format_input / shape_b   the same sweep in the wire format and BASELINE configs[4]'s 2048 x 128
+               shape through its own fused launch, each with its own algorithmic bytes and roofline fraction
   end_to_end   sectors/s through the 4-slot cascade: pinned H2D of the wire-format sector + decode +
                chain + D2H per sector, all ranks at once -- BASELINE.json's end-to-end figure
   cpu_baseline the oracle's fp32 port on this host's cores (all usable cores and one thread)
@@ -34,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 SETTLE_S = 0.3     # untimed launches before the W warm-up steps: the clocks reach their working point (see settle())
 
 
@@ -371,6 +373,63 @@ def main():
                 "what": "wrp_process_batch_raw_device: 12 B/sample big-endian int16 read by the tile workgroups (6 MiB/sector), wall clock"}
         del d_raw, d_out_w
 
+    # BASELINE configs[4] (2048 range gates x 128 pulses) through its own fused launch, on this GPU, in the default line: a
+    # second engine, its own sweep (360 x 4 MiB, distinct blocks), wall clock + HIP events + spot check against the oracle.
+    shape_b = None
+    if args.shape == "A" and not args.no_extras:
+        mb, nb = 2048, 128
+        with wrp_amd.Engine(device=dev_index, n_slots=1, n_sectors=1, n_elevations=1, m=mb, n=nb) as eb:
+            pool_b = np.stack([O.synthetic_sector((rank * S + k) % 4096, mb, nb, C) for k in range(8)])
+            d_pb = torch.from_numpy(pool_b.view(np.float32).reshape(8, -1)).to(dev)
+            d_iq_b = d_pb[torch.arange(S, device=dev) % 8].contiguous()
+            d_out_b = torch.empty((S, mb // 2, 2), dtype=torch.float32, device=dev)
+            del d_pb
+            t_end = time.perf_counter() + args.settle
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    eb.process_batch_device(d_iq_b.data_ptr(), S, d_out_b.data_ptr())
+                eb.check()
+            bsteps = max(10, min(args.steps, 100))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(bsteps):
+                eb.process_batch_device(d_iq_b.data_ptr(), S, d_out_b.data_ptr())
+            eb.check()
+            barrier()
+            bdt = max_over_ranks(time.perf_counter() - t0)
+            b_ok = True
+            for k in (0, S - 1):
+                got = d_out_b[k].cpu().numpy()
+                want = O.sector(pool_b[k % 8][0], pool_b[k % 8][1], dtype=np.float64)
+                b_ok = b_ok and bool(np.isneginf(got[0, 0]) and np.max(np.abs(got[1:] - want[1:])) < 1e-3)
+            for _ in range(10):
+                eb.process_batch_device(d_iq_b.data_ptr(), S, d_out_b.data_ptr())
+            b_iters = max(3, min(args.steps, 20))
+            b_ms = eb.time_batch_device(d_iq_b.data_ptr(), S, d_out_b.data_ptr(), b_iters)[0]
+            balgo = eb.algorithmic_bytes
+            b_ach = balgo * S * b_iters / (b_ms * 1e-3) / 1e9
+            b_traffic, b_note = None, "no traffic file for this build"
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_B.json")))
+                if tj.get("fingerprint") != wrp_amd.source_fingerprint():
+                    b_note = "profiles/%s/traffic_B.json was measured on other sources (fingerprint differs)" % PROFILE_ROUND
+                elif tj.get("sectors_per_launch") != S or not tj.get("fused"):
+                    b_note = "profiles/%s/traffic_B.json was measured on another configuration" % PROFILE_ROUND
+                else:
+                    b_traffic, b_note = round(tj["bytes_per_launch"]), tj.get("source", "")
+            except Exception:
+                pass
+            shape_b = {"value": round(world * S * bsteps / bdt, 1), "unit": "sectors/s", "steps": bsteps,
+                       "workload": f"BASELINE configs[4]: C=2, m=2048 range gates, n=128 pulses, fp32 complex, {S} sectors per launch, device-resident",
+                       "kernel": "fused_chain_2048x128", "fused_fallbacks": eb.fused_fallbacks,
+                       "algorithmic_bytes_per_sector": balgo, "algorithmic_bytes_per_launch": balgo * S,
+                       "avg_launch_us": round(b_ms * 1e3 / b_iters, 2), "achieved": round(b_ach, 1), "peak": HBM_PEAK_GBS,
+                       "frac": round(b_ach / HBM_PEAK_GBS, 4), "traffic": b_traffic, "traffic_note": b_note,
+                       "frac_wall_clock": round(balgo * S * bsteps / bdt / 1e9 / HBM_PEAK_GBS, 4), "spot_check_vs_oracle": b_ok,
+                       "what": "`value`: wall clock over `steps` launches; `achieved` / `frac`: HIP events on the engine's stream over "
+                               "%d launches, as the headline's roofline" % b_iters}
+            del d_iq_b, d_out_b
+
     # end to end: every sector crosses PCIe.  Wire-format sector (12 B/sample, big-endian int16, 6 MiB) in
     # the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB, 4 slots cascading, all ranks at once.
     end_to_end = None
@@ -436,7 +495,7 @@ def main():
                                 f"sweep per GPU per step, device-resident") if args.shape == "A" else
                                (f"shape B = BASELINE configs[4] (C=2, m=2048 range gates, n=128 pulses, fp32 complex), {S} sectors "
                                 f"per GPU per step, device-resident"), "sectors_per_step_per_gpu": S,
-                   "parallelism": f"sector-sharded x{world}, no collective (gloo barrier + MAX only)",
+                   "parallelism": f"sector-sharded x{world}, no collective (barrier + MAX of the elapsed time over a TCP store)",
                    "launch": "fused" if fused else "two kernels", "untimed_settle_s": args.settle},
         "achieved_hbm_GBps": round(world * achieved, 1),
         "spot_check_vs_oracle": ok,
@@ -446,6 +505,8 @@ def main():
     }
     if wire is not None:
         line["wire_format_input"] = wire
+    if shape_b is not None:
+        line["shape_b"] = shape_b
     if end_to_end is not None:
         line["end_to_end"] = end_to_end
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

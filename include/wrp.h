@@ -147,7 +147,10 @@ int wrp_result(wrp_handle h, int sector, int elevation, const float **zdb_zdr);
  * planar and big-endian behind their header and the slot's D2H copy delivers them wire-ready: *frame points INTO the
  * pinned frame table (which = 0: Zdb, 1: Zdr; with_elevation selects the 4-byte or the 2-byte header; *bytes = 4*(m/2)
  * + 4 or + 2) -- send it as it is.  Valid after wrp_wait of the slot that processed (sector, elevation), until that
- * pair is submitted again. */
+ * pair is submitted again OR the next wrp_result_frame call for the same (sector, elevation, which): the two header forms
+ * share their bytes (the call rewrites bytes 0..3 of the frame in place), so a frame is fetched, sent, and only then
+ * fetched in its other form; one thread per handle, as everywhere in this ABI.  The 2-byte form starts 2 bytes into a
+ * word: its floats are not 4-byte aligned (it is a byte string for a socket). */
 int wrp_result_frame(wrp_handle h, int sector, int elevation, int which, int with_elevation, const unsigned char **frame,
                      size_t *bytes);
 
@@ -161,22 +164,46 @@ int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, floa
  * vhQ as big-endian int16 (sector.cpp:52-62) -- what wrp_pinned_raw_slot takes, for a whole sweep that already lies in
  * device memory.  m = 1024, n = 512, >= WRP_FUSED_MIN_SECTORS sectors: the tile workgroups of the persistent launch read
  * the samples themselves (byte swap + conversion in registers, in place of the fp32 loads): 6 MiB of HBM reads per sector
- * instead of 8 and no decode pass.  Otherwise the batch is decoded 8 sectors at a time and runs the two kernels.  Results
- * are bit-identical to Sector::fromByteArray + the scatter of rpv2.cu:372-383 + wrp_process_batch_device. */
+ * instead of 8 and no decode pass.  m = 2048, n = 128: the batch is decoded on the GPU (up to max_batch sectors at a time)
+ * in front of that shape's persistent launch.  Otherwise (small batches, other shapes, WRP_FLAG_TWO_KERNELS) it is
+ * decoded in front of the two kernels.  Results are bit-identical to Sector::fromByteArray + the scatter of
+ * rpv2.cu:372-383 + wrp_process_batch_device. */
 int wrp_process_batch_raw_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *stream);
+
+/* Egress framing for batches (rpv2.cu:631-661, read_single.cc:510-520).  The batch entries above with one
+ * more output: d_frames = [n_sectors][2][1 + m/2] 32-bit words in device memory -- per sector the Zdb frame, then the Zdr
+ * frame, each a header word followed by m/2 BIG-ENDIAN floats, written by the same lanes that write d_out (all launch
+ * forms).  d_headers = [n_sectors] header words in device memory, copied as they are in front of both frames of their
+ * sector: wrp_frame_header(sector, elevation) gives the word whose bytes are [sector BE16][elevation BE16] (rpv2.cu's
+ * topics "B" / "C"); for the 2-byte header of read_single.cc pass wrp_frame_header(x, sector) and send from byte 2.
+ * Frame (s, which) = the 4 * (1 + m/2) bytes at d_frames + (2 s + which) * (1 + m/2) words.  Same completion rules as
+ * d_out (below). */
+uint32_t wrp_frame_header(int sector, int elevation);
+int wrp_process_batch_framed_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *d_frames,
+                                    const uint32_t *d_headers, void *stream);
+int wrp_process_batch_raw_framed_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *d_frames,
+                                        const uint32_t *d_headers, void *stream);
 
 /* Completion and ordering.  The batch is ordered on the stream it is given (NULL: the engine's own stream);
  * ONE fused launch is in flight per handle: a batch on another stream first waits, on the device, for the
  * previous one.  wrp_check waits for every batch submitted so far.
  * The fused launch needs all its workgroups resident at once and says so, within milliseconds, when they
- * are not (e.g. another kernel occupies CUs); such a batch is REPEATED on the two-kernel path -- by
- * wrp_check, or by the next wrp_process_batch_device once the launch has completed -- so d_out is valid
- * once wrp_check has returned WRP_OK, and must not be consumed before that.  The handle then stays on the
- * two kernels for 16 batches and tries the fused launch again; wrp_last_hip_error holds a note,
- * wrp_fused_fallbacks the count of repeated batches.  wrp_process_host and wrp_time_batch_device check by
- * themselves. */
+ * are not (e.g. another kernel occupies CUs); such a batch is REPEATED on the two-kernel path:
+ *   - a batch given a CALLER's stream: the repeat is queued on that stream right behind the launch, gated on the
+ *     launch's status word in device memory (it costs a few microseconds when the launch has succeeded).  STREAM ORDER
+ *     IS ENOUGH: when the stream has passed the batch, d_out (and d_frames) are right, and d_iq / d_raw may be
+ *     reused -- like any other asynchronous work on a stream; wrp_check is not needed for correctness.
+ *   - a batch on the engine's own stream (stream = NULL): only this library can wait for that stream.  wrp_check (or the
+ *     next batch call, once the launch has completed) repeats a launch that gave up, re-reading d_iq / d_raw: outputs
+ *     are valid when wrp_check has returned WRP_OK, and the INPUT MUST STAY VALID AND UNMODIFIED UNTIL THEN.
+ * After a launch that gave up the handle stays on the two kernels for 16 batches and then tries the fused launch again;
+ * wrp_last_hip_error holds the note of the first failure of such a run, wrp_fused_fallbacks counts the repeated batches
+ * (launches that were already queued behind the failed one fail on its status and are repeated, and counted, too).
+ * wrp_process_host and wrp_time_batch_device check by themselves. */
 int wrp_check(wrp_handle h);
 int wrp_fused_fallbacks(wrp_handle h);
+/* Batches (or pieces of batches) that were issued as a fused launch so far -- which path a batch took (tests, harnesses). */
+int wrp_fused_launches(wrp_handle h);
 
 /* Synchronous convenience: host buffers in the same layouts (pageable or pinned). */
 int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *out_host);

@@ -124,9 +124,16 @@ def load_library():
     lib.wrp_process_host.argtypes = [vp, vp, i, vp]
     if hasattr(lib, "wrp_process_batch_raw_device"):
         lib.wrp_process_batch_raw_device.argtypes = [vp, vp, i, vp, vp]
+    if hasattr(lib, "wrp_process_batch_framed_device"):
+        lib.wrp_process_batch_framed_device.argtypes = [vp, vp, i, vp, vp, vp, vp]
+        lib.wrp_process_batch_raw_framed_device.argtypes = [vp, vp, i, vp, vp, vp, vp]
+        lib.wrp_frame_header.argtypes = [i, i]
+        lib.wrp_frame_header.restype = C.c_uint32
     lib.wrp_check.argtypes = [vp]
     if hasattr(lib, "wrp_fused_fallbacks"):      # absent from older builds that tools/ab.py may load beside this one
         lib.wrp_fused_fallbacks.argtypes = [vp]
+    if hasattr(lib, "wrp_fused_launches"):
+        lib.wrp_fused_launches.argtypes = [vp]
     lib.wrp_debug_fused_mid.argtypes = [vp, vp, i, vp, vp, C.c_size_t]
     lib.wrp_dump_stage.argtypes = [vp, i, i, i, vp]
     lib.wrp_time_batch_device.argtypes = [vp, vp, i, vp, i, fp, fp, fp]
@@ -260,6 +267,15 @@ class Engine:
         self._check(self.lib.wrp_process_batch_raw_device(self._h, C.c_void_p(d_raw_ptr), n_sectors, C.c_void_p(d_out_ptr),
                                                           C.c_void_p(stream or 0)), "wrp_process_batch_raw_device")
 
+    def process_batch_framed_device(self, d_in_ptr, n_sectors, d_out_ptr, d_frames_ptr, d_headers_ptr, stream=None, raw=False):
+        """The batch entries with the products framed for the wire (N2): d_frames [S][2][1 + m/2] words, d_headers [S] words."""
+        fn = self.lib.wrp_process_batch_raw_framed_device if raw else self.lib.wrp_process_batch_framed_device
+        self._check(fn(self._h, C.c_void_p(d_in_ptr), n_sectors, C.c_void_p(d_out_ptr), C.c_void_p(d_frames_ptr),
+                       C.c_void_p(d_headers_ptr), C.c_void_p(stream or 0)), fn.__name__)
+
+    def frame_header(self, sector, elevation):
+        return int(self.lib.wrp_frame_header(sector, elevation))
+
     def check(self):
         """Wait for every batch submitted so far (a fused launch that gave up is repeated on the two-kernel path here)."""
         self._check(self.lib.wrp_check(self._h), "wrp_check")
@@ -267,6 +283,10 @@ class Engine:
     @property
     def fused_fallbacks(self):
         return self.lib.wrp_fused_fallbacks(self._h)
+
+    @property
+    def fused_launches(self):
+        return self.lib.wrp_fused_launches(self._h)
 
     def time_batch_device(self, d_iq_ptr, n_sectors, d_out_ptr, iters, per_kernel=False):
         """HIP-event timing on the engine's own stream -> (ms_total, ms_range, ms_doppler)."""

@@ -13,193 +13,10 @@ namespace wrp {
 
 typedef float2 cf;
 
-#ifndef WRP_PACKED_MATH
-#define WRP_PACKED_MATH 0      // 1: every complex add / scale / multiply is one v_pk_*_f32 (bit-identical, NOT faster: see below)
-#endif
-#if WRP_PACKED_MATH
-// ---- packed form (an experiment that stays in the tree because it is the proof of what bounds the launches): a complex
-// value is an even-aligned register pair and every complex add, subtract, scale and multiply is ONE v_pk_*_f32 (two with
-// the product) -- the same IEEE operations on the same operands as the scalar form below, so the results are
-// bit-identical (checked on the GPU: tools/ab.py prints it); the rotations by +-i and the half swaps ride on the
-// instructions' op_sel / neg modifiers.  The fused 1024 x 512 kernel has 28 % fewer vector instructions in this form
-// (2503 -> 1791 static) and runs at the SAME speed (+0.2 %; 2048 x 128 +3.6 %, wire format -1.8 %: profiles/r03/
-// ab_packed_math.log): a packed f32 instruction occupies the SIMD as long as the two it replaces (tools/valubench.hip),
-// and in the phases where the launch does arithmetic its SIMDs are busy -- what bounds those phases is the SIMD's
-// cycles, not the rate at which a wave can issue.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk(cf a) { return (v2f){a.x, a.y}; }
-__device__ __forceinline__ cf unpk(v2f a) { return make_float2(a.x, a.y); }
-
-__device__ __forceinline__ cf cadd(cf a, cf b) { return unpk(pk(a) + pk(b)); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return unpk(pk(a) - pk(b)); }
-__device__ __forceinline__ cf cscale(cf a, float w) { return unpk(pk(a) * (v2f){w, w}); }
-// a * w, w in registers:  (a.x w.x, a.x w.y), then (-a.y w.y + ., a.y w.x + .)
-__device__ __forceinline__ cf cmul(cf a, cf w)
-{
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(pk(a)), "v"(pk(w)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(pk(a)), "v"(pk(w)), "v"(t));
-    return unpk(r);
-}
-// a * w, w a compile-time constant: fma(a.y, -w.y, .) is fma(-a.y, w.y, .), and the compiler keeps (-w.y, w.x) in scalar registers
-__device__ __forceinline__ cf cmul_const(cf a, cf w)
-{
-    const v2f t = (v2f){a.x, a.x} * pk(w);
-    return unpk(__builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-w.y, w.x}, t));
-}
-// a + SIGN*i*b and a - SIGN*i*b
-template <int SIGN>
-__device__ __forceinline__ cf cadd_rot(cf a, cf b)
-{
-    v2f r;
-    if (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(pk(a)), "v"(pk(b)));
-    else          asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(pk(a)), "v"(pk(b)));
-    return unpk(r);
-}
-template <int SIGN>
-__device__ __forceinline__ cf csub_rot(cf a, cf b) { return cadd_rot<-SIGN>(a, b); }
-// a * (SIGN * i) on its own (where no add follows that could carry it)
-template <int SIGN>
-__device__ __forceinline__ cf mul_si(cf a)
-{
-    return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
-}
-// (a.x - SIGN a.y, SIGN a.x + a.y) = a (1 + SIGN i), without the 1/sqrt2
-template <int SIGN>
-__device__ __forceinline__ v2f one_plus_si(cf a)
-{
-    v2f r;    // SIGN > 0: (a.x - a.y, a.x + a.y);  SIGN < 0: (a.x + a.y, a.y - a.x)
-    if (SIGN > 0) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(r) : "v"(pk(a)));
-    else          asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(pk(a)));
-    return r;
-}
-// SIGN > 0: (a.x + a.y, a.x - a.y);  SIGN < 0: (a.y - a.x, a.x + a.y)
-template <int SIGN>
-__device__ __forceinline__ v2f sums_w8_3(cf a)
-{
-    v2f r;
-    if (SIGN > 0) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(pk(a)));
-    else          asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(r) : "v"(pk(a)));
-    return r;
-}
-// a * exp(SIGN * i*pi/4)
-template <int SIGN>
-__device__ __forceinline__ cf mul_w8_1(cf a)
-{
-    constexpr float h = 0.70710678118654752440f;
-    return unpk(one_plus_si<SIGN>(a) * (v2f){h, h});
-}
-// a * exp(SIGN * 3*i*pi/4):  SIGN > 0: (-(a.x + a.y) h, (a.x - a.y) h);  SIGN < 0: ((a.y - a.x) h, -(a.x + a.y) h)
-template <int SIGN>
-__device__ __forceinline__ cf mul_w8_3(cf a)
-{
-    constexpr float h = 0.70710678118654752440f;
-    const v2f s = sums_w8_3<SIGN>(a);         // (-p) h = p (-h): the sign rides on the constant
-    return unpk(SIGN > 0 ? s * (v2f){-h, h} : s * (v2f){h, -h});
-}
-
-template <int SIGN>
-__device__ __forceinline__ void fft2(cf &a, cf &b)
-{
-    cf t = a;
-    a = cadd(t, b);
-    b = csub(t, b);
-}
-
-// 4-point: X1 = (x0 - x2) + SIGN*i*(x1 - x3).  X2ROT: x2 stands for SIGN*i*x2 (the rotation rides on the first adds)
-template <int SIGN, bool X2ROT = false>
-__device__ __forceinline__ void fft4(cf &x0, cf &x1, cf &x2, cf &x3)
-{
-    const cf t0 = X2ROT ? cadd_rot<SIGN>(x0, x2) : cadd(x0, x2), t1 = X2ROT ? csub_rot<SIGN>(x0, x2) : csub(x0, x2);
-    const cf t2 = cadd(x1, x3), d = csub(x1, x3);
-    x0 = cadd(t0, t2);
-    x2 = csub(t0, t2);
-    x1 = cadd_rot<SIGN>(t1, d);
-    x3 = csub_rot<SIGN>(t1, d);
-}
-
-template <int SIGN>
-__device__ __forceinline__ void fft8(cf (&v)[8])
-{
-    constexpr float h = 0.70710678118654752440f;
-    cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
-    fft4<SIGN>(e0, e1, e2, e3);
-    fft4<SIGN>(o0, o1, o2, o3);
-    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-    v[2] = cadd_rot<SIGN>(e2, o2); v[6] = csub_rot<SIGN>(e2, o2);
-    {   // e1 +- h o1 (1 + SIGN*i)
-        const v2f s = one_plus_si<SIGN>(o1), hh = {h, h};
-        v[1] = unpk(__builtin_elementwise_fma(s, hh, pk(e1)));
-        v[5] = unpk(__builtin_elementwise_fma(-s, hh, pk(e1)));
-    }
-    {   // e3 +- h o3 (-1 + SIGN*i), the sums formed as the scalar form forms them:  SIGN > 0: s = (x + y, x - y), v3 = e3 + h (-s.x, s.y);
-        // SIGN < 0: s = (x - y, x + y), v3 = e3 - h s.  fma(-p, h, e) = fma(p, -h, e): the signs ride on the constants
-        const v2f s = SIGN > 0 ? sums_w8_3<1>(o3) : one_plus_si<1>(o3);
-        const v2f h3 = SIGN > 0 ? (v2f){-h, h} : (v2f){-h, -h}, h7 = SIGN > 0 ? (v2f){h, -h} : (v2f){h, h};
-        v[3] = unpk(__builtin_elementwise_fma(s, h3, pk(e3)));
-        v[7] = unpk(__builtin_elementwise_fma(s, h7, pk(e3)));
-    }
-}
-
-// the first level of fft16 on inputs that still want their real weights: x_i = w_i a_i.  w0 a0 +- w2 a2 is one product and
-// two fused multiply-adds per component instead of two products, an add and a subtract: 20 instructions instead of 24
-template <int SIGN>
-__device__ __forceinline__ void fft4_scaled(cf &x0, cf &x1, cf &x2, cf &x3, float w0, float w1, float w2, float w3)
-{
-    const v2f s2 = pk(x2) * (v2f){w2, w2}, s3 = pk(x3) * (v2f){w3, w3};
-    const cf t0 = unpk(__builtin_elementwise_fma(pk(x0), (v2f){w0, w0}, s2)), t1 = unpk(__builtin_elementwise_fma(pk(x0), (v2f){w0, w0}, -s2));
-    const cf t2 = unpk(__builtin_elementwise_fma(pk(x1), (v2f){w1, w1}, s3)), d = unpk(__builtin_elementwise_fma(pk(x1), (v2f){w1, w1}, -s3));
-    x0 = cadd(t0, t2);
-    x2 = csub(t0, t2);
-    x1 = cadd_rot<SIGN>(t1, d);
-    x3 = csub_rot<SIGN>(t1, d);
-}
-template <int SIGN> __device__ __forceinline__ void fft16_tail(cf (&v)[16]);
-template <int SIGN>
-__device__ __forceinline__ void fft16(cf (&v)[16])
-{
-#pragma unroll
-    for (int r = 0; r < 4; r++) fft4<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12]);
-    fft16_tail<SIGN>(v);
-}
-// fft16 of (w[r] s) * v[r] (the window of the range stage: row weight x column weight): the weights ride on the first
-// level, each product w[r] s formed where it is used
-template <int SIGN>
-__device__ __forceinline__ void fft16_scaled(cf (&v)[16], const float (&w)[16], float s)
-{
-#pragma unroll
-    for (int r = 0; r < 4; r++) fft4_scaled<SIGN>(v[r], v[r + 4], v[r + 8], v[r + 12], w[r] * s, w[r + 4] * s, w[r + 8] * s, w[r + 12] * s);
-    fft16_tail<SIGN>(v);
-}
-template <int SIGN>
-__device__ __forceinline__ void fft16_tail(cf (&v)[16])
-{
-    constexpr float c1 = 0.92387953251128675613f; // cos(pi/8)
-    constexpr float s1 = 0.38268343236508977173f; // sin(pi/8)
-    constexpr float sg = (float)SIGN;
-    v[5] = cmul_const(v[5], make_float2(c1, sg * s1));
-    v[6] = mul_w8_1<SIGN>(v[6]);
-    v[7] = cmul_const(v[7], make_float2(s1, sg * c1));
-    v[9] = mul_w8_1<SIGN>(v[9]);
-    v[11] = mul_w8_3<SIGN>(v[11]);                     // v[10] * SIGN*i rides on the butterfly below
-    v[13] = cmul_const(v[13], make_float2(s1, sg * c1));
-    v[14] = mul_w8_3<SIGN>(v[14]);
-    v[15] = cmul_const(v[15], make_float2(-c1, -sg * s1));
-    fft4<SIGN>(v[0], v[1], v[2], v[3]);
-    fft4<SIGN>(v[4], v[5], v[6], v[7]);
-    fft4<SIGN, true>(v[8], v[9], v[10], v[11]);
-    fft4<SIGN>(v[12], v[13], v[14], v[15]);
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = a + 1; b < 4; b++) {
-            cf t = v[4 * a + b];
-            v[4 * a + b] = v[4 * b + a];
-            v[4 * b + a] = t;
-        }
-}
-#else
+// (A packed form -- every complex add / scale / multiply as ONE v_pk_*_f32, rotations on op_sel / neg modifiers -- was
+// built and measured in round 3: 28 % fewer vector instructions in the fused kernel, bit-identical output, the SAME speed
+// (profiles/r03/ab_packed_math.log): a packed f32 instruction occupies the SIMD as long as the two it replaces.  It is in
+// the history of this file.)
 __device__ __forceinline__ cf cscale(cf a, float w) { return make_float2(a.x * w, a.y * w); }
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -344,6 +161,5 @@ __device__ __forceinline__ void fft16_tail(cf (&v)[16])
         }
 }
 
-#endif
 
 } // namespace wrp

@@ -42,7 +42,7 @@ struct Slot {
 
 constexpr int WRP_RING = 64;            // fused batches that may be outstanding (status words, events)
 constexpr int WRP_FUSED_COOLDOWN = 16;  // batches on the two-kernel path after a fused launch that gave up
-constexpr int WRP_RAW_CHUNK = 8;        // sectors decoded at a time when a wire-format batch runs the two kernels
+constexpr int WRP_DECODE_MIN = 8;       // smallest decode workspace (sectors): it grows on demand up to max_batch sectors
 
 struct FusedLane {
     wrp::FusedCtl *d_ctl = nullptr;
@@ -51,7 +51,11 @@ struct FusedLane {
     bool used = false;
     bool ctl_dirty = true;              // memset before the next launch (first launch, after a failure)
 };
-struct FusedBatch { const float2 *in; int n; float *out; int slot; bool raw; };   // raw: `in` is the wire format
+// the optional wire-ready output of a batch: frames [S][2][1 + m/2] words, hdrs [S] header words (both device)
+struct Frames { unsigned *frames = nullptr; const unsigned *hdrs = nullptr; };
+// raw: `in` is the wire format.  gated: the two-kernel repeat is already queued on the batch's stream behind the launch,
+// gated on the launch's status word in device memory -- the host only takes note of a failure
+struct FusedBatch { const float2 *in; int n; float *out; int slot; bool raw; bool gated; Frames fr; };
 
 } // namespace
 
@@ -80,6 +84,8 @@ struct wrp_engine {
     bool fused_armed = false;       // ... and it is in use (false for WRP_FUSED_COOLDOWN batches after one that gave up)
     int fused_cooldown = 0;
     int fused_fallbacks = 0;        // batches that were repeated on the two-kernel path
+    int fused_launches = 0;         // fused launches issued (introspection: wrp_fused_launches)
+    int fused_cascaded = 0;         // ... of which: launches queued behind a failed one that failed on its sticky status
     int n_cus = 0;
     FusedLane lane;
     hipEvent_t ev_ring[WRP_RING] = {};   // completion of fused batch `slot`
@@ -93,7 +99,8 @@ struct wrp_engine {
     bool batch_pending = false;
     float2 *d_mid = nullptr;  // [max_batch][2][m/2][n]
     int max_batch = 0;
-    float2 *d_decode = nullptr;   // [WRP_RAW_CHUNK][C][m][n]: wire-format batches that do not take the fused launch (allocated on first use)
+    float2 *d_decode = nullptr;   // [decode_cap][C][m][n]: wire-format batches in front of kernels that read the planar block (allocated on first use)
+    int decode_cap = 0;
     // slots + host result table [elev][sector][gate][2]
     std::vector<Slot> slots;
     float *h_result = nullptr; // pinned
@@ -117,8 +124,8 @@ namespace {
 
 bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 int ilog2(int x) { int b = 0; while ((1 << b) < x) b++; return b; }
-// m = 1024, n = 512 (the 00iq.altb shape) runs the tuned kernels; every other power-of-two shape
-// up to 2048 x 1024 (e.g. config 5's 2048 x 128) runs the generic kernels of wrp_generic.h.
+// m = 1024, n = 512 (the 00iq.altb shape) and m = 2048, n = 128 (BASELINE configs[4]) run tuned kernels (wrp_fused.h,
+// wrp_kernels.h / wrp_fused_b.h, wrp_shape_b.h); every other power-of-two shape up to 2048 x 1024 runs wrp_generic.h.
 bool shape_supported(int m, int n) { return is_pow2(m) && is_pow2(n) && m >= 64 && m <= 2048 && n >= 32 && n <= 1024; }
 bool shape_tuned(int m, int n) { return m == 1024 && n == 512; }
 
@@ -152,18 +159,19 @@ void make_taps(int count, wrp::MaTaps &t)
 
 template <int TCOLS, bool DUMP>
 void launch_range_t(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, hipStream_t st,
-                    const wrp::DumpPtrs &d)
+                    const wrp::DumpPtrs &d, const unsigned *gate)
 {
     typedef wrp::RangeTile<TCOLS> T;
     const wrp_config &c = h->cfg;
     const dim3 grid(n_sectors * 2 * (c.n / TCOLS)), block(T::THREADS);
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
     hipLaunchKernelGGL((wrp::range_pass_1024<TCOLS, DUMP>), grid, block, T::LDS_BYTES, st, d_iq, d_mid, rc, c.n,
-                       c.channels, d);
+                       c.channels, d, gate);
 }
 
+// gate (device pointer or nullptr): the launch only runs when *gate != 0 (kernels: gate_closed)
 void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, hipStream_t st,
-                  const wrp::DumpPtrs *dump)
+                  const wrp::DumpPtrs *dump, const unsigned *gate = nullptr)
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
@@ -172,7 +180,7 @@ void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mi
         const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
         const int total = n_sectors * 2 * (wrp::RB_N / 16), grid = std::min(total, h->n_cus);
         hipLaunchKernelGGL(wrp::range_pass_2048, dim3(grid), dim3(wrp::RangeTileB::THREADS), wrp::RangeTileB::LDS_BYTES, st, d_iq,
-                           d_mid, rc, h->cfg.channels, total);
+                           d_mid, rc, h->cfg.channels, total, gate);
         return;
     }
     if (!h->tuned) {
@@ -196,47 +204,50 @@ void launch_range(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mi
             typedef wrp::RangeTile<8> T;
             const int total = n_sectors * 2 * (c.n / 8), grid = std::min(total, (2 * h->n_cus) & ~15);
             hipLaunchKernelGGL(wrp::range_pass_1024_persistent<8>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, st, d_iq,
-                               d_mid, rc, c.n, c.channels, total);
+                               d_mid, rc, c.n, c.channels, total, gate);
         } else {
             typedef wrp::RangeTile<16> T;
             const int total = n_sectors * 2 * (c.n / 16), grid = std::min(total, h->n_cus & ~15);
             hipLaunchKernelGGL(wrp::range_pass_1024_persistent<16>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, st, d_iq,
-                               d_mid, rc, c.n, c.channels, total);
+                               d_mid, rc, c.n, c.channels, total, gate);
         }
         return;
     }
     if (h->range_tcols == 8) {
-        if (dump) launch_range_t<8, true>(h, d_iq, n_sectors, d_mid, st, *dump);
-        else launch_range_t<8, false>(h, d_iq, n_sectors, d_mid, st, none);
+        if (dump) launch_range_t<8, true>(h, d_iq, n_sectors, d_mid, st, *dump, gate);
+        else launch_range_t<8, false>(h, d_iq, n_sectors, d_mid, st, none, gate);
     } else {
-        if (dump) launch_range_t<16, true>(h, d_iq, n_sectors, d_mid, st, *dump);
-        else launch_range_t<16, false>(h, d_iq, n_sectors, d_mid, st, none);
+        if (dump) launch_range_t<16, true>(h, d_iq, n_sectors, d_mid, st, *dump, gate);
+        else launch_range_t<16, false>(h, d_iq, n_sectors, d_mid, st, none, gate);
     }
 }
 
 template <bool DUMP, int TAPS>
 void launch_doppler_t(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_out, hipStream_t st,
-                      const wrp::DumpPtrs &d)
+                      const wrp::DumpPtrs &d, const unsigned *gate)
 {
     const wrp_config &c = h->cfg;
     const dim3 grid(c.m / 2 / wrp::DP_WAVES, n_sectors), block(wrp::DP_WAVES * 64);
     hipLaunchKernelGGL((wrp::doppler_pass_512<DUMP, TAPS>), grid, block, 0, st, d_mid, d_out, h->d_tw_n_arr,
-                       c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, d);
+                       c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, d, gate);
 }
 
+// frames + frame_hdr: the slot path (sector 0 of the launch); fr: the batch entries (every sector, header table)
 void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_out, hipStream_t st,
-                    const wrp::DumpPtrs *dump, unsigned *frames = nullptr, unsigned frame_hdr = 0)
+                    const wrp::DumpPtrs *dump, unsigned *frames = nullptr, unsigned frame_hdr = 0, Frames fr = Frames{},
+                    const unsigned *gate = nullptr)
 {
     wrp::DumpPtrs none{};
     none.channel = -1;
-    none.frames = frames;        // (the dump launches never frame: wrp_dump_stage)
+    none.frames = fr.frames ? fr.frames : frames;        // (the dump launches never frame: wrp_dump_stage)
     none.frame_hdr = frame_hdr;
+    none.frame_hdrs = fr.frames ? fr.hdrs : nullptr;
     if (h->tuned_b && !(dump && (dump->hamm || dump->fft1))) {
         const wrp_config &c = h->cfg;
         const dim3 grid(c.m / 2 / (wrp::DB_WAVES * 2), n_sectors), block(wrp::DB_WAVES * 64);
 #define WRP_DOPPLER_B(TAPS, DUMP)                                                                                    \
     hipLaunchKernelGGL((wrp::doppler_pass_128<TAPS, DUMP>), grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps, \
-                       c.k_range_resolution, c.k_calibration, dump ? *dump : none)
+                       c.k_range_resolution, c.k_calibration, dump ? *dump : none, gate)
         if (h->taps_pad == 7) { if (dump) WRP_DOPPLER_B(7, true); else WRP_DOPPLER_B(7, false); }
         else { if (dump) WRP_DOPPLER_B(9, true); else WRP_DOPPLER_B(9, false); }
 #undef WRP_DOPPLER_B
@@ -256,17 +267,26 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
         return;
     }
     if (h->taps_pad == 7) {
-        if (dump) launch_doppler_t<true, 7>(h, d_mid, n_sectors, d_out, st, *dump);
-        else launch_doppler_t<false, 7>(h, d_mid, n_sectors, d_out, st, none);
+        if (dump) launch_doppler_t<true, 7>(h, d_mid, n_sectors, d_out, st, *dump, gate);
+        else launch_doppler_t<false, 7>(h, d_mid, n_sectors, d_out, st, none, gate);
     } else {
-        if (dump) launch_doppler_t<true, 9>(h, d_mid, n_sectors, d_out, st, *dump);
-        else launch_doppler_t<false, 9>(h, d_mid, n_sectors, d_out, st, none);
+        if (dump) launch_doppler_t<true, 9>(h, d_mid, n_sectors, d_out, st, *dump, gate);
+        else launch_doppler_t<false, 9>(h, d_mid, n_sectors, d_out, st, none, gate);
     }
+}
+
+size_t sector_elems(const wrp_config &c) { return (size_t)c.channels * c.m * c.n; }
+size_t mid_elems(const wrp_config &c) { return (size_t)2 * (c.m / 2) * c.n; }
+size_t frame_words(const wrp_config &c) { return (size_t)2 * (1 + c.m / 2); }   // the two framed products of one sector
+Frames frames_at(Frames fr, const wrp_config &c, int sector)
+{
+    if (fr.frames) { fr.frames += (size_t)sector * frame_words(c); fr.hdrs += sector; }
+    return fr;
 }
 
 // one persistent launch for the whole batch: XCD teams keep the intermediate in their L2 (wrp_fused.h)
 int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_sectors, float *d_out, hipStream_t st, int slot,
-                 unsigned long long *d_stamps = nullptr, bool raw = false)
+                 unsigned long long *d_stamps = nullptr, bool raw = false, Frames fr = Frames{})
 {
     const wrp_config &c = h->cfg;
     // a successful launch leaves the control block zeroed (fused_leave): no memset node in front of the next one
@@ -278,11 +298,13 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
     // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
     if (h->tuned_b) {
-#define WRP_FUSED_B(TAPS)                                                                                             \
-    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS>), dim3(grid), dim3(wrp::FUSED_THREADS), wrp::FusedTileB::LDS_BYTES, st, \
-                       d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, c.channels, h->taps,           \
-                       c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps)
-        if (h->taps_pad == 7) WRP_FUSED_B(7); else WRP_FUSED_B(9);
+#define WRP_FUSED_B(TAPS, STAMPS)                                                                                     \
+    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
+                       wrp::FusedTileB::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, \
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
+                       fr.frames, fr.hdrs)
+        if (d_stamps) { if (h->taps_pad == 7) WRP_FUSED_B(7, true); else WRP_FUSED_B(9, true); }
+        else { if (h->taps_pad == 7) WRP_FUSED_B(7, false); else WRP_FUSED_B(9, false); }
 #undef WRP_FUSED_B
         HIP_TRY(h, hipGetLastError());
         return WRP_OK;
@@ -291,7 +313,8 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
 #define WRP_FUSED_RAW(TAPS)                                                                                           \
     hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, false, true>), dim3(grid), dim3(wrp::FUSED_THREADS),          \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
-                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, nullptr)
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, nullptr,       \
+                       fr.frames, fr.hdrs)
         if (h->taps_pad == 7) WRP_FUSED_RAW(7); else WRP_FUSED_RAW(9);
 #undef WRP_FUSED_RAW
         HIP_TRY(h, hipGetLastError());
@@ -300,7 +323,8 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
 #define WRP_FUSED(TAPS, STAMPS)                                                                                       \
     hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
-                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps)
+                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
+                       fr.frames, fr.hdrs)
     if (d_stamps) {
         if (h->taps_pad == 7) WRP_FUSED(7, true); else WRP_FUSED(9, true);
     } else {
@@ -311,59 +335,114 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
     return WRP_OK;
 }
 
-int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
-                 hipStream_t st, const wrp::DumpPtrs *dump, unsigned *frames = nullptr, unsigned frame_hdr = 0);
-size_t sector_elems(const wrp_config &c);
-
-// the two-kernel path over a whole batch, in chunks of max_batch sectors, on stream st (shared workspace d_mid: the
-// stream first waits for the previous two-kernel batch)
-int launch_two_kernel_batch(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t st)
+// range pass + Doppler pass.  frames / frame_hdr: the slot path's framed products (sector 0 of the launch); fr: a batch's;
+// gate: see launch_range
+int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out, hipStream_t st,
+                 const wrp::DumpPtrs *dump, unsigned *frames = nullptr, unsigned frame_hdr = 0, Frames fr = Frames{},
+                 const unsigned *gate = nullptr)
 {
-    const wrp_config &c = h->cfg;
+    launch_range(h, d_iq, n_sectors, d_mid, st, dump, gate);
+    launch_doppler(h, d_mid, n_sectors, d_out, st, dump, frames, frame_hdr, fr, gate);
+    HIP_TRY(h, hipGetLastError());
+    return WRP_OK;
+}
+
+// The workspaces every batch path shares -- d_mid (two kernels) and d_decode (wire-format batches in front of kernels that
+// read the planar block) -- are handed from batch to batch through ONE event: a batch that uses either first makes its
+// stream wait for the previous user, and leaves the event behind it.
+int workspace_acquire(wrp_engine *h, hipStream_t st)
+{
     if (h->batch_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_batch, 0));
-    for (int s0 = 0; s0 < n_sectors; s0 += h->max_batch) {
-        const int cnt = std::min(h->max_batch, n_sectors - s0);
-        const int rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
-        if (rc != WRP_OK) return rc;
-    }
+    return WRP_OK;
+}
+int workspace_release(wrp_engine *h, hipStream_t st)
+{
     HIP_TRY(h, hipEventRecord(h->ev_batch, st));
     h->batch_pending = true;
     return WRP_OK;
 }
 
-// a wire-format batch on the two-kernel path: WRP_RAW_CHUNK sectors at a time are decoded (decode_wire) and transformed
-int launch_two_kernel_raw_batch(wrp_engine *h, const unsigned char *raw, int n_sectors, float *d_out, hipStream_t st)
+// the two-kernel path over a whole batch, in chunks of max_batch sectors, on stream st
+int launch_two_kernel_batch(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t st, Frames fr = Frames{},
+                            const unsigned *gate = nullptr)
 {
     const wrp_config &c = h->cfg;
-    const int count = c.m * c.n;
-    if (!h->d_decode) HIP_TRY(h, hipMalloc(&h->d_decode, sizeof(float2) * sector_elems(c) * WRP_RAW_CHUNK));
-    if (h->batch_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_batch, 0));   // d_decode and d_mid are shared workspaces
-    for (int s0 = 0; s0 < n_sectors; s0 += WRP_RAW_CHUNK) {
-        const int cnt = std::min(WRP_RAW_CHUNK, n_sectors - s0);
-        hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256, cnt), dim3(256), 0, st,
-                           (const unsigned *)(raw + (size_t)s0 * count * 12), h->d_decode, count, c.channels);
-        const int rc = launch_chain(h, h->d_decode, cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr);
-        if (rc != WRP_OK) return rc;
+    int rc = workspace_acquire(h, st);
+    for (int s0 = 0; rc == WRP_OK && s0 < n_sectors; s0 += h->max_batch) {
+        const int cnt = std::min(h->max_batch, n_sectors - s0);
+        rc = launch_chain(h, in + (size_t)s0 * sector_elems(c), cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr,
+                          nullptr, 0, frames_at(fr, c, s0), gate);
     }
-    HIP_TRY(h, hipEventRecord(h->ev_batch, st));
-    h->batch_pending = true;
+    return rc != WRP_OK ? rc : workspace_release(h, st);
+}
+
+// the decode workspace holds at least `sectors` sectors (at most max_batch are ever asked for); growing it waits for the device
+int ensure_decode(wrp_engine *h, int sectors)
+{
+    sectors = std::min(h->max_batch, std::max(sectors, std::min(h->max_batch, WRP_DECODE_MIN)));
+    if (h->decode_cap >= sectors) return WRP_OK;
+    if (h->d_decode) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        (void)hipFree(h->d_decode);
+        h->d_decode = nullptr;
+        h->decode_cap = 0;
+    }
+    HIP_TRY(h, hipMalloc(&h->d_decode, sizeof(float2) * sector_elems(h->cfg) * (size_t)sectors));
+    h->decode_cap = sectors;
     return WRP_OK;
+}
+void launch_decode(wrp_engine *h, const unsigned char *raw, int cnt, hipStream_t st, const unsigned *gate = nullptr)
+{
+    const int count = h->cfg.m * h->cfg.n;
+    hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256, cnt), dim3(256), 0, st, (const unsigned *)raw, h->d_decode, count,
+                       h->cfg.channels, gate);
+}
+
+// a wire-format batch on the two-kernel path: decode_wire + the two kernels, as many sectors at a time as both workspaces hold
+int launch_two_kernel_raw_batch(wrp_engine *h, const unsigned char *raw, int n_sectors, float *d_out, hipStream_t st,
+                                Frames fr = Frames{}, const unsigned *gate = nullptr)
+{
+    const wrp_config &c = h->cfg;
+    const size_t count = (size_t)c.m * c.n;
+    int rc = ensure_decode(h, n_sectors);
+    if (rc == WRP_OK) rc = workspace_acquire(h, st);
+    for (int s0 = 0; rc == WRP_OK && s0 < n_sectors; s0 += h->decode_cap) {
+        const int cnt = std::min(h->decode_cap, n_sectors - s0);    // decode_cap <= max_batch: d_mid holds them too
+        launch_decode(h, raw + (size_t)s0 * count * 12, cnt, st, gate);
+        rc = launch_chain(h, h->d_decode, cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr, nullptr, 0,
+                          frames_at(fr, c, s0), gate);
+    }
+    return rc != WRP_OK ? rc : workspace_release(h, st);
 }
 
 // A fused launch that gave up (bounded wait, or the CUs did not host 32 tile + 32 row workgroups per XCD: another kernel
-// on the GPU) has said so in its own pinned status word.  Its output is void: the batch is computed again, here and
-// synchronously, by the two kernels; the handle stays on them for WRP_FUSED_COOLDOWN batches and then tries again.
-int redo_batch(wrp_engine *h, const FusedBatch &b, unsigned status)
+// on the GPU) has said so in its own pinned status word.  Its output is void.  The handle leaves the fused launch alone
+// for WRP_FUSED_COOLDOWN batches and then tries again.  The FIRST failure of a run leaves its note; launches that were
+// queued behind it fail on its sticky status and are only counted.
+void note_fused_failure(wrp_engine *h, unsigned status)
 {
+    const bool cascade = !h->fused_armed && h->fused_cooldown > 0;
     h->fused_armed = false;
     h->fused_cooldown = WRP_FUSED_COOLDOWN;
     h->fused_fallbacks++;
     h->lane.ctl_dirty = true;
-    const std::string note = (status & 2)
+    if (cascade) {
+        h->fused_cascaded++;
+        return;
+    }
+    h->hip_err = (status & 2)
         ? "fused launch: an XCD did not host 32 tile + 32 row workgroups; batch repeated on the two-kernel path"
         : "fused launch: a bounded wait gave up (workgroups not co-resident?); batch repeated on the two-kernel path";
-    int rc = b.raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)b.in, b.n, b.out, h->stream)
-                   : launch_two_kernel_batch(h, b.in, b.n, b.out, h->stream);
+}
+// ... and the batch is computed again by the two kernels: here and synchronously (batches on the engine's own stream), or
+// by the gated launches that are already queued behind it on the caller's stream (submit_fused)
+int redo_batch(wrp_engine *h, const FusedBatch &b, unsigned status)
+{
+    note_fused_failure(h, status);
+    if (b.gated) return WRP_OK;
+    const std::string note = h->hip_err;
+    int rc = b.raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)b.in, b.n, b.out, h->stream, b.fr)
+                   : launch_two_kernel_batch(h, b.in, b.n, b.out, h->stream, b.fr);
     if (rc != WRP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->batch_pending = false;
@@ -395,40 +474,69 @@ int reap_fused(wrp_engine *h, bool block, size_t leave = 0)
     return WRP_OK;
 }
 
-// fused launch of one batch; stream = the caller's or nullptr (the engine's)
-int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream, bool raw = false)
+// fused launch of (a piece of) one batch; stream = the caller's or nullptr (the engine's).
+// On a CALLER's stream the two-kernel repeat is queued right behind the launch, gated on the launch's status word in
+// device memory (its workgroups return at once when the launch has succeeded): d_out is right when the stream says so,
+// whether or not the host ever looks (stream order alone; include/wrp.h).  On the engine's own stream nothing but
+// wrp_check can wait for the batch, and wrp_check repeats a failed launch itself: no gated launches there.
+int submit_fused_piece(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream, bool raw, Frames fr)
 {
+    hipStream_t st = stream ? stream : h->stream;
     if (h->outstanding.size() >= (size_t)WRP_RING) {
         const int rc = reap_fused(h, true, WRP_RING - 1);
         if (rc != WRP_OK) return rc;
-        if (!h->fused_armed)
-            return raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, stream ? stream : h->stream)
-                       : launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? stream : h->stream);
+        if (!h->fused_armed)      // one of them had given up: this batch takes the two kernels
+            return raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, st, fr)
+                       : launch_two_kernel_batch(h, in, n_sectors, d_out, st, fr);
     }
     FusedLane &lane = h->lane;
-    hipStream_t st = stream ? stream : h->stream;
     if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // control block and slots are free again (free on one stream)
     const int slot = h->ring_next;
     h->ring_next = (h->ring_next + 1) % WRP_RING;
-    const int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot, nullptr, raw);
+    const bool decode_first = raw && h->tuned_b;   // 2048 x 128: the batch is decoded, then its fused launch reads the planar block
+    int rc = WRP_OK;
+    if (decode_first) {
+        rc = workspace_acquire(h, st);
+        if (rc != WRP_OK) return rc;
+        launch_decode(h, (const unsigned char *)in, n_sectors, st);
+    }
+    rc = launch_fused(h, lane, decode_first ? h->d_decode : in, n_sectors, d_out, st, slot, nullptr, raw && !decode_first, fr);
     if (rc != WRP_OK) return rc;
+    h->fused_launches++;
     HIP_TRY(h, hipEventRecord(h->ev_ring[slot], st));
+    if (decode_first) {
+        rc = workspace_release(h, st);
+        if (rc != WRP_OK) return rc;
+    }
+    if (stream) {
+        const unsigned *gate = &lane.d_ctl->status;
+        rc = raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, st, fr, gate)
+                 : launch_two_kernel_batch(h, in, n_sectors, d_out, st, fr, gate);
+        if (rc != WRP_OK) return rc;
+    }
     HIP_TRY(h, hipEventRecord(lane.done, st));
     lane.used = true;
-    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, raw});
+    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, raw, stream != nullptr, fr});
     return WRP_OK;
 }
 
-int launch_chain(wrp_engine *h, const float2 *d_iq, int n_sectors, float2 *d_mid, float *d_out,
-                 hipStream_t st, const wrp::DumpPtrs *dump, unsigned *frames, unsigned frame_hdr)
+// one batch through the fused launch; a wire-format batch of the 2048 x 128 shape goes piece by piece (decode workspace)
+int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream, bool raw = false, Frames fr = Frames{})
 {
-    launch_range(h, d_iq, n_sectors, d_mid, st, dump);
-    launch_doppler(h, d_mid, n_sectors, d_out, st, dump, frames, frame_hdr);
-    HIP_TRY(h, hipGetLastError());
-    return WRP_OK;
+    if (!(raw && h->tuned_b)) return submit_fused_piece(h, in, n_sectors, d_out, stream, raw, fr);
+    const wrp_config &c = h->cfg;
+    int rc = ensure_decode(h, n_sectors);
+    const unsigned char *raw_bytes = (const unsigned char *)in;
+    for (int s0 = 0; rc == WRP_OK && s0 < n_sectors; s0 += h->decode_cap) {
+        const int cnt = std::min(h->decode_cap, n_sectors - s0);
+        const float2 *piece = (const float2 *)(raw_bytes + (size_t)s0 * c.m * c.n * 12);
+        float *out = d_out + (size_t)s0 * (c.m / 2) * 2;
+        if (cnt >= WRP_FUSED_MIN_SECTORS && h->fused_armed) rc = submit_fused_piece(h, piece, cnt, out, stream, true, frames_at(fr, c, s0));
+        else rc = launch_two_kernel_raw_batch(h, (const unsigned char *)piece, cnt, out, stream ? stream : h->stream, frames_at(fr, c, s0));
+    }
+    return rc;
 }
 
-size_t sector_elems(const wrp_config &c) { return (size_t)c.channels * c.m * c.n; }
 // [sector BE16][elevation BE16] as one little-endian word of device / host memory
 unsigned frame_header_word(int sector, int elevation)
 {
@@ -439,7 +547,6 @@ unsigned *frames_of(wrp_engine *h, int sector, int elevation)
 {
     return h->h_frames + ((size_t)elevation * h->cfg.n_sectors + sector) * 2 * (1 + h->cfg.m / 2);
 }
-size_t mid_elems(const wrp_config &c) { return (size_t)2 * (c.m / 2) * c.n; }
 
 int destroy_impl(wrp_engine *h)
 {
@@ -494,10 +601,12 @@ int create_impl(wrp_engine *h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
     // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
     h->fused = (h->tuned || h->tuned_b) && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<7>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES));
+#define WRP_FUSED_B_ATTR(TAPS, STAMPS)                                                                    \
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<TAPS, STAMPS>), \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES))
+    WRP_FUSED_B_ATTR(7, false); WRP_FUSED_B_ATTR(9, false);
+    WRP_FUSED_B_ATTR(7, true);  WRP_FUSED_B_ATTR(9, true);
+#undef WRP_FUSED_B_ATTR
     h->fused_armed = h->fused;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
     if ((c.flags & 0xff) == 0) h->range_tcols = h->persist ? 16 : 8;   // best measured tile for each form
@@ -526,7 +635,7 @@ int create_impl(wrp_engine *h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES));
     HIP_TRY(h, hipEventCreateWithFlags(&h->lane.done, hipEventDisableTiming));
     HIP_TRY(h, hipMalloc(&h->lane.d_ctl, sizeof(wrp::FusedCtl)));
-    HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS * WRP_FUSED_B_SLOTS));   // (x 2 in the two-slot experiment of wrp_fused_b.h)
+    HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
     for (auto &e : h->ev_ring) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(h, hipHostMalloc(&h->h_status, sizeof(unsigned) * WRP_RING, hipHostMallocMapped));
     std::memset(h->h_status, 0, sizeof(unsigned) * WRP_RING);
@@ -716,7 +825,7 @@ int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(s.d_raw, s.h_raw, (size_t)count * 12, hipMemcpyHostToDevice, s.stream));
     hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256), dim3(256), 0, s.stream,
-                       (const unsigned *)s.d_raw, s.d_iq, count, c.channels);
+                       (const unsigned *)s.d_raw, s.d_iq, count, c.channels, (const unsigned *)nullptr);
     int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr, s.d_frames, frame_header_word(sector, elevation));
     if (rc != WRP_OK) return rc;
     float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
@@ -764,36 +873,50 @@ int wrp_result_frame(wrp_handle h, int sector, int elevation, int which, int wit
     return WRP_OK;
 }
 
-int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream)
+// one batch, planar or wire format, with or without framed products: the fused launch where the shape, the size and the
+// handle's state allow it, the two kernels otherwise
+static int process_batch(wrp_handle h, const void *d_in, bool raw, int n_sectors, float *d_out, Frames fr, void *stream)
 {
-    if (!h || !d_iq || !d_out || n_sectors < 0) return WRP_ERR_INVALID;
+    if (!h || !d_in || !d_out || n_sectors < 0 || (fr.frames && !fr.hdrs)) return WRP_ERR_INVALID;
     if (n_sectors == 0) return WRP_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    const float2 *in = (const float2 *)d_iq;
     // every entry of the batch path looks at the fused launches that have completed since the last look
     int rc = reap_fused(h, false);
     if (rc != WRP_OK) return rc;
-    if (h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS) return submit_fused(h, in, n_sectors, d_out, (hipStream_t)stream);
-    rc = launch_two_kernel_batch(h, in, n_sectors, d_out, stream ? (hipStream_t)stream : h->stream);
+    if (h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS) return submit_fused(h, (const float2 *)d_in, n_sectors, d_out, (hipStream_t)stream, raw, fr);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    rc = raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)d_in, n_sectors, d_out, st, fr)
+             : launch_two_kernel_batch(h, (const float2 *)d_in, n_sectors, d_out, st, fr);
     if (rc == WRP_OK && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
         h->fused_armed = true;     // the fused launch gets another chance
     return rc;
 }
 
+int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream)
+{
+    return process_batch(h, d_iq, false, n_sectors, d_out, Frames{}, stream);
+}
+
 int wrp_process_batch_raw_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *stream)
 {
-    if (!h || !d_raw || !d_out || n_sectors < 0) return WRP_ERR_INVALID;
-    if (n_sectors == 0) return WRP_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
-    int rc = reap_fused(h, false);
-    if (rc != WRP_OK) return rc;
-    if (h->tuned && h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS)
-        return submit_fused(h, (const float2 *)d_raw, n_sectors, d_out, (hipStream_t)stream, true);
-    rc = launch_two_kernel_raw_batch(h, (const unsigned char *)d_raw, n_sectors, d_out, stream ? (hipStream_t)stream : h->stream);
-    if (rc == WRP_OK && h->tuned && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
-        h->fused_armed = true;
-    return rc;
+    return process_batch(h, d_raw, true, n_sectors, d_out, Frames{}, stream);
 }
+
+int wrp_process_batch_framed_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *d_frames,
+                                    const uint32_t *d_headers, void *stream)
+{
+    if (!d_frames || !d_headers) return WRP_ERR_INVALID;
+    return process_batch(h, d_iq, false, n_sectors, d_out, Frames{(unsigned *)d_frames, (const unsigned *)d_headers}, stream);
+}
+
+int wrp_process_batch_raw_framed_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *d_frames,
+                                        const uint32_t *d_headers, void *stream)
+{
+    if (!d_frames || !d_headers) return WRP_ERR_INVALID;
+    return process_batch(h, d_raw, true, n_sectors, d_out, Frames{(unsigned *)d_frames, (const unsigned *)d_headers}, stream);
+}
+
+uint32_t wrp_frame_header(int sector, int elevation) { return frame_header_word(sector, elevation); }
 
 int wrp_check(wrp_handle h)
 {
@@ -809,6 +932,7 @@ int wrp_check(wrp_handle h)
 }
 
 int wrp_fused_fallbacks(wrp_handle h) { return h ? h->fused_fallbacks : 0; }
+int wrp_fused_launches(wrp_handle h) { return h ? h->fused_launches : 0; }
 
 int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *stream)
 {
@@ -830,7 +954,7 @@ int wrp_process_host(wrp_handle h, const void *iq_host, int n_sectors, float *ou
     if (e != hipSuccess) { (void)hipFree(d_in); h->hip_err = "hipMalloc(out)"; return WRP_ERR_NOMEM; }
     int rc = WRP_OK;
     e = hipMemcpyAsync(d_in, iq_host, in_bytes, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) rc = wrp_process_batch_device(h, d_in, n_sectors, d_out, h->stream);
+    if (e == hipSuccess) rc = wrp_process_batch_device(h, d_in, n_sectors, d_out, nullptr);   // the engine's own stream
     if (e == hipSuccess && rc == WRP_OK) rc = wrp_check(h);     // waits; a fused launch that gave up is repeated here
     if (e == hipSuccess && rc == WRP_OK) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -974,7 +1098,7 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
                            unsigned long long *host_stamps, size_t host_count)
 {
     if (!h || !d_iq || !d_out || !host_stamps || n_sectors <= 0) return WRP_ERR_INVALID;
-    if (!h->tuned && !h->tuned_b) return WRP_ERR_UNSUPPORTED;   // (2048 x 128 stamps only in a -DWRP_EXP_B_STAMPS build: zeros otherwise)
+    if (!h->tuned && !h->tuned_b) return WRP_ERR_UNSUPPORTED;
     const size_t count = (size_t)h->n_cus * 2 * wrp::FUSED_STAMP_TASKS * wrp::FUSED_STAMPS;
     if (host_count < count) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

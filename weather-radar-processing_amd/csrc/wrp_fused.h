@@ -65,60 +65,15 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_MEMBERS = 32;                  // tile members = row members per team = CUs per XCD
 constexpr int FUSED_MAX_TEAMS = 8;                 // XCDs of the device this is written for
 constexpr int FUSED_STAMP_TASKS = 16;
-// Row waves and the hand-over flags (profiles/r03/ab_polling.log, us/sector, one process, builds interleaved):
-//   every row wave polls the L2 itself, s_sleep 1 between polls (round 2's form)          2.469
-//   the same, s_sleep 4                                                                     2.459   <- kept
-//   ONE wave per half polls and wakes the other three through an LDS word + s_wakeup        2.631 (sleep 1), 2.593 (sleep 4)
-// The scalar instructions of the polls are 85 % of the launch's scalar instructions, but what a row wave buys with them is
-// the time at which it NOTICES a half: the tile members wait at their look for the slowest row wave of the team, and every
-// tenth of a microsecond added to a notice is added to the task (a poller costs 6 %).
-#ifndef WRP_FUSED_POLL_SLEEP
-#define WRP_FUSED_POLL_SLEEP 1
-#endif
-#ifndef WRP_FUSED_WAIT_SLEEP
-#define WRP_FUSED_WAIT_SLEEP 16      // (poller form only) s_sleep units of a row wave that waits for its half's poller
-#endif
-#ifndef WRP_FUSED_ROW_SPLIT
-#define WRP_FUSED_ROW_SPLIT 1       // 1: every row wave serves both halves, one row of each; 0: four waves per half, two rows each
-#endif
-#ifndef WRP_FUSED_ROW_PRIO
-#define WRP_FUSED_ROW_PRIO 3        // s_setprio level of a row wave between its notice of a half and its `loaded` flag (0: off)
-#endif
-#ifndef WRP_FUSED_INPUT_AUX
-#define WRP_FUSED_INPUT_AUX 2       // cache policy of the planar input loads: AUX_NT
-#endif
-// How the next tile is requested (profiles/r03/ab_request_pacing.log; us/sector in one process, builds interleaved):
-//   0: in QUARTERS (4 loads per lane at 4 points of the task: round 2)        2.465
-//   1: in EIGHTHS  (2 loads at 8 points)                                      2.353
-//   2: ONE load at a time, sixteen pieces over twelve points of the task      2.330   <- kept
-// The launch with its loads dropped by a zero-record descriptor runs at 1.74: what the input costs is not HBM time (tiles
-// served by the Infinity Cache: 2.39) and not a wait for the data (stage 1 starts on time in either build) -- the tile
-// waves stall where they ISSUE a burst of requests into a CU memory pipeline that holds a bounded number of misses
-// (profiles/r03/fused_stamps_loads_vs_noloads.log: the phases that contain request points grow, the others do not).
-#ifndef WRP_FUSED_EIGHTHS
-#define WRP_FUSED_EIGHTHS 2
-#endif
-#ifndef WRP_FUSED_CU_KINDS
-#define WRP_FUSED_CU_KINDS 0        // 1: tile CUs and row CUs (two workgroups of ONE kind per CU); 0: a tile and a row workgroup on every CU
-#endif
-#ifndef WRP_FUSED_UNIFORM_W
-#define WRP_FUSED_UNIFORM_W 1
-#endif
-#if WRP_FUSED_UNIFORM_W    // the wave's index as a scalar: its share of the LDS addresses is scalar arithmetic
-#define WRP_W(tid) wave_id()
-#else
-#define WRP_W(tid) ((tid) >> 6)
-#endif
-#ifndef WRP_FUSED_ROW_KEEP_TW
-#define WRP_FUSED_ROW_KEEP_TW 1
-#endif
-#ifndef WRP_FUSED_ROW_POLLERS
-#define WRP_FUSED_ROW_POLLERS 0     // 1: one wave per half polls the L2 and wakes the other three (measured slower: above)
-#endif
+// The measured choices below (alternatives, numbers and logs: DESIGN.md 4.1; the rejected forms are in the history of this
+// file, `git log -- weather-radar-processing_amd/csrc/wrp_fused.h`, and in profiles/r03/ab_*.log):
+//   * every row wave polls the L2 itself with s_sleep 1 between polls, and serves both halves, one gate of each;
+//   * the next tile is requested ONE load at a time, sixteen pieces over twelve points of the task, non-temporally;
+//   * a row wave runs from its notice of a half to its `loaded` flag at s_setprio 3.
 constexpr unsigned long long FUSED_JOIN_TICKS = 400000ull;   // 4 ms of s_memrealtime (100 MHz): deadline of the team meeting
-constexpr int FUSED_INPUT_AUX = WRP_FUSED_INPUT_AUX;
-constexpr int FUSED_ROW_PRIO = WRP_FUSED_ROW_PRIO;
-constexpr int FUSED_POLL_SLEEP = WRP_FUSED_POLL_SLEEP;   // s_sleep units (64 cycles) between two polls of a row wave
+constexpr int FUSED_INPUT_AUX = AUX_NT;   // cache policy of the planar input loads: the stream must not push the slot out of the L2
+constexpr int FUSED_ROW_PRIO = 3;         // s_setprio level of a row wave between its notice of a half and its `loaded` flag
+constexpr int FUSED_POLL_SLEEP = 1;       // s_sleep units (64 cycles) between two polls of a row wave
 constexpr int FUSED_STAMPS = 9;   // 0..7 phase stamps per task, 8: identity (task 0)
 constexpr int FUSED_SLOT_ROWS = RP_M / 4;                          // 256: the gates of ONE half
 constexpr size_t FUSED_TEAM_ELEMS = (size_t)FUSED_SLOT_ROWS * DP_N;   // float2 units: ONE slot[256][512] = 1 MiB per team
@@ -136,7 +91,7 @@ struct FusedCtl {               // zeroed by the host once; every launch leaves 
     unsigned pad0[30];
     unsigned census[2][8];      // workgroups per kind (0 tile, 1 row) and XCC
     unsigned done[8];           // workgroups of the XCC's team that have left the task loop
-    unsigned cu_count[8];       // (WRP_FUSED_CU_KINDS) CUs of the XCC seen so far: a CU's ordinal decides the kind of BOTH its workgroups
+    unsigned pad1[8];
     unsigned cu_arrivals[8][256];            // workgroups seen per physical CU (key = HW_ID bits 15:8: se, sh, cu)
     unsigned cu_block[8][256][2];            // blockIdx + 1 of the first and the second workgroup to arrive there
     FusedFlags stored[2][8][FUSED_MEMBERS];  // [half][xcc][line of row member r]: byte t = tasks whose half tile member t has stored
@@ -167,10 +122,7 @@ struct FusedTile {
     // row takes the other sixteen (SQ_LDS_BANK_CONFLICT 21.5 M -> 9.7 M per launch, 9.3 % -> 4.4 % of the LDS's active
     // cycles; the launch is no faster for it: stage 1 is bound by its arithmetic).  Every other access covers whole rows and
     // only sees its columns permuted.  The wire-format launch writes whole rows in stage 1 and keeps the plain order.
-#ifndef WRP_FUSED_SWIZZLE
-#define WRP_FUSED_SWIZZLE 1
-#endif
-    template <bool SWZ = true> static __device__ __forceinline__ int swz(int pos) { return SWZ && WRP_FUSED_SWIZZLE ? (pos & 1) : 0; }
+    template <bool SWZ = true> static __device__ __forceinline__ int swz(int pos) { return SWZ ? (pos & 1) : 0; }
     // Stage-1 twiddles W_1024^{p0 k1} ARRANGED in the 64 pads so that a lane reads its fifteen at ONE base + immediate
     // offsets, and the eight positions p0 = 8 w .. 8 w + 7 of a wave are 64 contiguous bytes (no bank conflict): pad
     // 8 (p0 >> 3) + (k1 >> 1), byte 64 (k1 & 1) + 8 (p0 & 7).
@@ -242,23 +194,6 @@ __device__ __forceinline__ bool spin_flags(const FusedFlags *line, unsigned seq,
     return false;
 }
 
-// Row waves that do not poll the L2 themselves: the half's polling wave writes the task number it has seen published into
-// an LDS word and pings the workgroup (s_wakeup ends the other waves' s_sleep early), so the sleepers can sleep long --
-// three of four row waves leave the scalar unit, the scalar cache and the L2 alone while they wait (the polls of all
-// eight row waves were 85 % of the launch's 679 k scalar instructions per sector).  A ping that arrives between a
-// wave's look and its s_sleep is lost: that wave then sleeps its 16 x 64 cycles out, once.
-__device__ __forceinline__ bool wait_lds_word(lds_word *word, int want)
-{
-#pragma unroll 1
-    for (unsigned spins = 0; spins < FUSED_SPIN_BUDGET; spins++) {
-        const int v = __builtin_amdgcn_readfirstlane(*word);
-        if (v >= want) return true;
-        if (v < 0) return false;
-        __builtin_amdgcn_s_sleep(WRP_FUSED_WAIT_SLEEP);
-    }
-    return false;
-}
-
 // the same wait for a wave in the middle of a tile: no early return (an exit edge there costs the
 // tile loop 14 spilled registers); a wave that gave up remembers it (`failed`, wave-uniform), stops
 // waiting and runs on -- the launch is reported as failed through `status` and its output discarded
@@ -314,19 +249,6 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));   // recompute the lane offsets per call instead of keeping (spilling) them
     const int p0 = w * 8 + (l >> 3), cp = l & 7;
-#ifdef WRP_EXP_NOLOOK   // timing only: the tile members never wait for the rows (results may be wrong)
-#define WRP_EXP_LOOKSKIP(x) true
-#else
-#define WRP_EXP_LOOKSKIP(x) (x)
-#endif
-#ifdef WRP_EXP_NOPOLL   // timing only: the row members never wait for the tile members (results are wrong)
-#define WRP_EXP_POLLSKIP(x) true
-#else
-#define WRP_EXP_POLLSKIP(x) (x)
-#endif
-#ifdef WRP_EXP_NOLOAD   // timing only: what the launch costs without its input (results are wrong)
-    valid = false;
-#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
     const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
 #pragma unroll
@@ -334,7 +256,7 @@ __device__ __forceinline__ void fused_tile_load(const float2 *src /* wave-unifor
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
-// ONE row load (WRP_FUSED_EIGHTHS == 2: sixteen pieces over twelve request points).  The lane offset of the tile is computed
+// ONE row load (the next tile is asked for in sixteen pieces over twelve request points of the task).  The lane offset of the tile is computed
 // ONCE per task (fused_tile_voff) and kept in a register: recomputed at each of the sixteen points it was 6 % of the
 // launch's vector instructions.
 __device__ __forceinline__ int fused_tile_voff(int col_base)
@@ -348,29 +270,10 @@ template <int R>
 __device__ __forceinline__ void fused_tile_load1(const float2 *src /* wave-uniform */, int voff, const float *wd,
                                                  float4 (&v)[16], float2 &wdv, bool valid)
 {
-#ifdef WRP_EXP_NOLOAD
-    valid = false;
-#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
     v[R] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * R * DP_N * 8);
     if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (voff & (DP_N * 8 - 1)) >> 1, 0);   // (col_base + 2 cp) * 4
 }
-// an EIGHTH: rows r = E and E + 8 (WRP_FUSED_EIGHTHS: eight request points per task instead of four)
-template <int E>
-__device__ __forceinline__ void fused_tile_load8(const float2 *src /* wave-uniform */, int col_base, const float *wd,
-                                                 float4 (&v)[16], float2 &wdv, bool valid)
-{
-    const int w = wave_id();
-    int l = threadIdx.x & 63;
-    asm volatile("" : "+v"(l));
-    const int p0 = w * 8 + (l >> 3), cp = l & 7;
-    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RP_M * DP_N * 8u : 0u);
-    const int voff = (p0 * DP_N + col_base + cp * 2) * 8;
-    v[E] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * E * DP_N * 8);
-    v[E + 8] = buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * (E + 8) * DP_N * 8);
-    if (E == 7) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)DP_N * 4u), (col_base + cp * 2) * 4, 0);
-}
-
 // stage 1 (a2 + first radix of a3): window, radix 16 over rows p0 + 64 r, twiddle W_1024^{p0 k1};
 // k1 < 8 goes to the LDS image (group 0), k1 >= 8 stays in ga / gc (group 1).  The lane's two columns
 // are transformed ONE AFTER THE OTHER (and written as 8-byte halves of their 16-byte slots): both at
@@ -386,7 +289,7 @@ __device__ __forceinline__ void fused_stage1_tables(const unsigned char *smem, F
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // per-lane LDS addresses are recomputed per tile, not hoisted + spilled
     tid &= FUSED_THREADS - 1;       // (the compiler knows the range again: address arithmetic folds)
-    const int w = WRP_W(tid), l = tid & 63;
+    const int w = wave_id(), l = tid & 63;
     const int p0 = w * 8 + (l >> 3);
     const unsigned char *tw1 = smem + T::tw1_addr(p0, 0);   // k1 further on: a compile-time offset
 #pragma unroll
@@ -407,7 +310,7 @@ __device__ __forceinline__ void fused_stage1(unsigned char *smem, const float4 (
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, cp = l & 7;
+    const int w = wave_id(), l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
     const int slot = T::addr(p0, cp) + 8 * (COLUMN ^ T::swz(p0));   // position k1*64 + p0 is 8 k1 blocks further on (same parity)
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
@@ -432,20 +335,14 @@ __device__ __forceinline__ void fused_group1_to_lds(unsigned char *smem, const c
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, cp = l & 7;
+    const int w = wave_id(), l = tid & 63, cp = l & 7;
     const int p0 = w * 8 + (l >> 3);
-#if WRP_FUSED_SWIZZLE
     const int first = T::addr(p0, cp) + 8 * T::swz(p0), second = T::addr(p0, cp) + 8 * (1 ^ T::swz(p0));   // two conflict-free b64 = one b128 in LDS cycles
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         *reinterpret_cast<float2 *>(smem + first + j * 8 * T::BLK_BYTES) = ga[j];
         *reinterpret_cast<float2 *>(smem + second + j * 8 * T::BLK_BYTES) = gc[j];
     }
-#else
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        *reinterpret_cast<float4 *>(smem + T::addr(j * 64 + p0, cp)) = make_float4(ga[j].x, ga[j].y, gc[j].x, gc[j].y);
-#endif
 }
 
 // stages 2 and 3 of the sub-transform this WAVE owns in the current group (image rows w*64 ..) and
@@ -466,7 +363,7 @@ __device__ __forceinline__ void fused_stage2_item(unsigned char *smem)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, col = l & 15;
+    const int w = wave_id(), l = tid & 63, col = l & 15;
     // stage 2: radix 8 over positions p1 + 8 r (all of p1's parity), twiddle W_64^{p1 k2}, in place
     const int p1 = (l >> 4) + 4 * IT;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + (col ^ T::swz<SWZ>(p1)) * 8;   // position w*64 of this lane's column
@@ -495,7 +392,7 @@ __device__ __forceinline__ void fused_stage3_item(unsigned char *smem, cf (&o)[2
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, col = l & 15;
+    const int w = wave_id(), l = tid & 63, col = l & 15;
     unsigned char *base = smem + w * 8 * T::BLK_BYTES + col * 8, *base_odd = smem + w * 8 * T::BLK_BYTES + (col ^ T::swz<SWZ>(1)) * 8;
     const int k2 = (l >> 4) + 4 * IT;     // stage 3: radix 8 over the 8 contiguous positions k2*8 + r
     cf a[8];
@@ -515,7 +412,7 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, col = l & 15;
+    const int w = wave_id(), l = tid & 63, col = l & 15;
     const rsrc_t rd = make_rsrc(mid, (unsigned)FUSED_SLOT_ROWS * DP_N * 8u);
     // slot row of gate k1 + 16 k2 + 128 k3 (k1 = w + 8 group, k2 = (l >> 4) + 4 it): (gate >> 4) * 8 + (gate & 7)
     const int voff = ((w + 8 * (l >> 4)) * DP_N + col_base + col) * 8;
@@ -560,28 +457,7 @@ __device__ __forceinline__ FusedSeat fused_join(FusedCtl *ctl, lds_word *s_ctl)
                 if (!other) __builtin_amdgcn_s_sleep(4);
             }
         }
-#if WRP_FUSED_CU_KINDS
-        // Specialised CUs: the first sixteen CUs of the XCD to report host two TILE workgroups each, the others two ROW
-        // workgroups.  (A CU's vector-memory pipeline is in order: beside a tile workgroup's HBM requests the L2 hits of the
-        // row workgroup -- which are in the hand-over chain every tile member waits for -- queue behind them.)
-        unsigned kind = a & 1u;
-        if (a == 0) {
-            const unsigned ord = __hip_atomic_fetch_add(&ctl->cu_count[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&ctl->cu_block[x][key][0], 0x80000000u | ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            kind = ord < (unsigned)FUSED_MEMBERS / 2 ? 0u : 1u;
-        } else if (a == 1 && other) {
-            unsigned first = other;       // what the first arriver left there: its block id, then 0x80000000 | ordinal
-#pragma unroll 1
-            while (!(first & 0x80000000u) && __builtin_amdgcn_s_memrealtime() - t_join < FUSED_JOIN_TICKS) {
-                first = __hip_atomic_load(&ctl->cu_block[x][key][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!(first & 0x80000000u)) __builtin_amdgcn_s_sleep(4);
-            }
-            if (!(first & 0x80000000u)) other = 0;
-            kind = (first & 0x7fffffffu) < (unsigned)FUSED_MEMBERS / 2 ? 0u : 1u;
-        }
-#else
         const unsigned kind = other ? (blockIdx.x + 1u < other ? 0u : 1u) : (a & 1u);
-#endif
         const unsigned rank = __hip_atomic_fetch_add(&ctl->census[kind][x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned teams = gridDim.x / (2u * FUSED_MEMBERS);
         int good = other != 0 && x < teams && gridDim.x == teams * 2u * FUSED_MEMBERS;
@@ -645,7 +521,7 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
     for (int e = tid; e < 256 / 4; e += FUSED_THREADS) z[e] = zero;
     z = reinterpret_cast<uint4 *>(ctl->cu_block[xcc]);
     for (int e = tid; e < 512 / 4; e += FUSED_THREADS) z[e] = zero;
-    if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; ctl->cu_count[xcc] = 0; }
+    if (tid == 0) { ctl->census[0][xcc] = 0; ctl->census[1][xcc] = 0; ctl->done[xcc] = 0; }
 }
 
 // ---- wire-format input: the tile workgroups read the sector as it arrives -------------------------------
@@ -708,7 +584,7 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, c = l & 15;
+    const int w = wave_id(), l = tid & 63, c = l & 15;
     const int p0 = w * 4 + (l >> 4) + 32 * ITEM;
     const int slot = T::addr(p0, c >> 1) + 8 * (c & 1);
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
@@ -738,7 +614,7 @@ __device__ __forceinline__ void fused_raw_group1_to_lds(unsigned char *smem, con
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
-    const int w = WRP_W(tid), l = tid & 63, c = l & 15;
+    const int w = wave_id(), l = tid & 63, c = l & 15;
     const int pq = w * 4 + (l >> 4);
     const int slot = T::addr(pq, c >> 1) + 8 * (c & 1);
 #pragma unroll
@@ -845,7 +721,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
     float k_rr, float k_cal, unsigned *host_status /* pinned host word of this launch */,
-    unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */)
+    unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */,
+    unsigned *frames /* optional (N2): [S][2][1 + 512] words, the products framed for the wire */, const unsigned *frame_hdrs /* [S] header words */)
 {
     typedef FusedTile T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -901,16 +778,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         // member: rotating the tiles makes that a transient of each member, which the slack of the
         // hand-overs absorbs, instead of four members that are always late.
         auto tile_col = [&](int q) { return ((rank + q) & (FUSED_MEMBERS - 1)) * 16; };
-#ifdef WRP_EXP_KEEPV    // timing only: the first tile stays in the registers for the whole launch -- real data, no requests
-#define WRP_KEEPV_OFF(x) (void)next
-#else
-#define WRP_KEEPV_OFF(x) x
-#endif
-#ifdef WRP_EXP_L2LOAD   // timing only: every tile comes from the SAME sector of the team (L2 / Infinity Cache hits, real data)
-        auto tile_src = [&](int q) { return iq + ((size_t)trank * channels + (q & 1)) * RP_M * (size_t)n; };
-#else
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * RP_M * (size_t)n; };
-#endif
         float4 v[16];
         float2 wdv;
         fused_tile_load<0>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);   // HBM requests first ...
@@ -955,7 +823,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             cf o[2][4];
             const int voff_next = fused_tile_voff(tile_col(q + 1));
 #define WRP_L1(R) fused_tile_load1<R>(next, voff_next, rc.wd, v, wdv, q + 1 < tasks)
-#if WRP_FUSED_EIGHTHS == 2
             WRP_L1(0); WRP_L1(8);
             fused_stage2_item<0>(smem);
             WRP_L1(4);
@@ -965,18 +832,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             WRP_L1(1);
             fused_stage3_item<1>(smem, o);
             WRP_L1(9);
-#elif WRP_FUSED_EIGHTHS
-            fused_tile_load8<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage2(smem);
-            fused_tile_load8<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage3(smem, o);
-            fused_tile_load8<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-#else
-            WRP_KEEPV_OFF(fused_tile_load<0>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
-            fused_stage2(smem);
-            WRP_KEEPV_OFF(fused_tile_load<1>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
-            fused_stage3(smem, o);
-#endif
             // The team's ONE slot (1 MiB: the 256 gates of a half x 512 pulses) takes half 0 and half 1 of every task in
             // turn; it still holds half 1 of task q-1 until every row member has those rows in registers.  One slot
             // instead of one per half: a rewritten buffer of 2 MiB per XCD does not stay in the 4 MiB L2 beside the
@@ -984,27 +839,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             // row loads is what every tile member waited for); 1 MiB does -- write-backs 3.5 -> 0.5 MB per sector at
             // the same speed.  The look comes as late as it can: one wave, in front of the barrier behind which the
             // stores go out.
-            spin_flags_sticky(my_loaded1, (unsigned)q, failed, WRP_EXP_LOOKSKIP(w != 0));
+            spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_store(mid, tile_col(q), 0, o);
             // BEHIND the stores, so that a counted wait can tell them apart: the scheduling barrier keeps the four loads
             // below the eight stores whatever alias analysis says about `iq` (restrict) and the descriptor
             __builtin_amdgcn_sched_barrier(0);
-#if WRP_FUSED_EIGHTHS == 2
             WRP_L1(5); WRP_L1(13); WRP_L1(2); WRP_L1(10);
-#elif WRP_FUSED_EIGHTHS
-            fused_tile_load8<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-            fused_tile_load8<4>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-#else
-            WRP_KEEPV_OFF(fused_tile_load<2>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
-#endif
             fused_group1_to_lds(smem, ga, gc);
             stamp(q, 2);
-#ifdef WRP_EXP_KEEPV
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
-#endif
             // ... and counted by the last wave to get here, without waiting for the barrier
             last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
@@ -1012,7 +856,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             stamp(q, 6);
             __syncthreads();                    // A3: group 1 is in the image
             stamp(q, 3);
-#if WRP_FUSED_EIGHTHS == 2
             WRP_L1(6);
             fused_stage2_item<0>(smem);
             WRP_L1(14);
@@ -1022,18 +865,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             WRP_L1(11);
             fused_stage3_item<1>(smem, o);
             WRP_L1(7); WRP_L1(15);
-#elif WRP_FUSED_EIGHTHS
-            fused_tile_load8<5>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage2(smem);
-            fused_tile_load8<6>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-            fused_stage3(smem, o);
-            fused_tile_load8<7>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks);
-#else
-            WRP_KEEPV_OFF(fused_tile_load<3>(next, tile_col(q + 1), rc.wd, v, wdv, q + 1 < tasks));
-            fused_stage2(smem);
-            fused_stage3(smem, o);
-#endif
-            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, WRP_EXP_LOOKSKIP(w != 0));
+            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             stamp(q, 7);
             __syncthreads();                    // A4: image free for the next stage 1; the slot is free for half 1 (the rows have half 0 of THIS task)
             fused_store(mid, tile_col(q), 1, o);
@@ -1049,17 +881,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         // =============================== row member ===============================
         // Eight independent waves, no workgroup barrier in the loop.  A wave polls the member's flag line itself (scalar
         // loads); the last of a half's waves to have its row(s) in registers (counted in LDS) counts the member as loaded.
-        // WRP_FUSED_ROW_SPLIT (default): every wave serves both halves, one gate each; 0: waves 0-3 own the member's 8
-        // gates of half 0 (two each), waves 4-7 those of half 1.
         float2 *wbuf = reinterpret_cast<float2 *>(smem) + (size_t)w * DP_ELEMS;
         float2 *s_twn = reinterpret_cast<float2 *>(smem + T::OFF_TWN);
         doppler_twiddles_to_lds(s_twn, tw_n, tid, FUSED_THREADS);
-        if (tid < 4) s_ctl[12 + tid] = 0;   // 12, 13: arrival counts of the halves; 14, 15: (poller form) tasks seen published, per half
+        if (tid < 4) s_ctl[12 + tid] = 0;   // 12, 13: arrival counts of the halves
         __syncthreads();
         DopplerTwiddles row_tw;     // the lane's fourteen twiddles stay in registers for all of the wave's rows (wrp_kernels.h)
-        if (WRP_FUSED_ROW_KEEP_TW) doppler_row_twiddles(s_twn, l, row_tw);
+        doppler_row_twiddles(s_twn, l, row_tw);
         const DumpPtrs nodump{};
-#if WRP_FUSED_ROW_SPLIT
         // Every wave serves BOTH halves, one row of each: a half is then loaded by eight waves with 8 requests each instead
         // of four waves with 16 -- the row loads sit in the hand-over chain the tile members wait for at their looks.  A wave
         // has finished its row of one half well before the other half is published (a row is ~2 us of the ~10 us task).
@@ -1072,7 +901,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             for (int g = 0; g < 2; g++) {
                 const int gate = rank * 16 + 8 * g + w;
                 if (g == 0) stamp(q, 0);
-                there = there && WRP_EXP_POLLSKIP(spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status));
+                there = there && spin_flags(&ctl->stored[g][xcc][rank], (unsigned)(q + 1), &ctl->status);
                 if (!there) break;                              // status is set: the launch is void
                 if (g == 0) stamp(q, 1);
                 // From the notice to the publication of `loaded` the wave runs at RAISED PRIORITY: these two dozen
@@ -1093,61 +922,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
                 __builtin_amdgcn_s_setprio(0);
                 if (g == 0) stamp(q, 2);
-#ifdef WRP_EXP_NOROW    // timing only: the rows are loaded and handed back, not transformed
-                const float s = x[0].x + x[7].y;
-#else
-                const float s = doppler_row<false, TAPS, WRP_FUSED_ROW_KEEP_TW != 0>(x, wbuf, s_twn, taps, l, gate, false, nodump, row_tw);
-#endif
+                const float s = doppler_row<false, TAPS, true>(x, wbuf, s_twn, taps, l, gate, false, nodump, row_tw);
                 if (g == 0) stamp(q, 3);
                 if ((q & 1) == 0) s_hh[g] = s;
-                else if (l == 0) reflectivity_store(&out[((size_t)(trank + (q >> 1) * teams) * gates + gate) * 2], gate, s_hh[g], s, k_rr, k_cal);
+                else if (l == 0) {
+                    const int sec = trank + (q >> 1) * teams;
+                    unsigned *fr = frames ? frames + (size_t)sec * 2 * (1 + gates) : nullptr;
+                    reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, s_hh[g], s, k_rr, k_cal, fr, gates, fr ? frame_hdrs[sec] : 0u);
+                }
             }
             if (!there) break;
         }
-#else
-        const int g = w >> 2;                                  // this wave's half
-        const int g0 = rank * 16 + 8 * g + 2 * (w & 3);        // its gates g0, g0 + 1
-        const FusedFlags *my_stored = &ctl->stored[g][xcc][rank];
-        float s_hh0 = 0.f, s_hh1 = 0.f;     // HH row sums of this wave's gates, waiting for the VV task
-#pragma unroll 1
-        for (int q = 0; q < tasks; q++) {
-            stamp(q, 0);
-#if WRP_FUSED_ROW_POLLERS
-            bool there;
-            if ((w & 3) == 0) {   // the half's poller
-                there = spin_flags(my_stored, (unsigned)(q + 1), &ctl->status);
-                if (l == 0) s_ctl[14 + g] = there ? q + 1 : -1;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
-            } else {
-                there = wait_lds_word(&s_ctl[14 + g], q + 1);
-            }
-            if (!there) break;                                                    // status is set: the launch is void
-#else
-            if (!spin_flags(my_stored, (unsigned)(q + 1), &ctl->status)) break;   // status is set: the launch is void
-#endif
-            stamp(q, 1);
-            cf x0[8], x1[8];
-            const int r0 = rank * 8 + 2 * (w & 3);                 // slot rows of the gates g0, g0 + 1 (either half)
-            doppler_load_row<AUX_SC1>(mid + (size_t)r0 * n, l, x0);
-            doppler_load_row<AUX_SC1>(mid + (size_t)(r0 + 1) * n, l, x1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
-            int last = 0;
-            if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 4 * q + 3;
-            if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
-            stamp(q, 2);
-            const float s0 = doppler_row<false, TAPS, WRP_FUSED_ROW_KEEP_TW != 0>(x0, wbuf, s_twn, taps, l, g0, false, nodump, row_tw);
-            const float s1 = doppler_row<false, TAPS, WRP_FUSED_ROW_KEEP_TW != 0>(x1, wbuf, s_twn, taps, l, g0 + 1, false, nodump, row_tw);
-            stamp(q, 3);
-            if ((q & 1) == 0) {
-                s_hh0 = s0;
-                s_hh1 = s1;
-            } else if (l == 0) {
-                float *o2 = &out[((size_t)(trank + (q >> 1) * teams) * gates + g0) * 2];
-                reflectivity_store(o2, g0, s_hh0, s0, k_rr, k_cal);
-                reflectivity_store(o2 + 2, g0 + 1, s_hh1, s1, k_rr, k_cal);
-            }
-        }
-#endif
         flush_stamps();
         fused_leave(ctl, host_status, xcc, s_ctl);
     }

@@ -33,12 +33,8 @@ struct FusedTileB {
     static constexpr int OFF_WR = IMG_BYTES;                      // float wr_c[1024]: the first half of the window
     static constexpr int OFF_CTL = OFF_WR + (RB_M / 2) * 4;       // 77824: control words, both kinds (as FusedTile)
     static constexpr int OFF_TW2 = OFF_CTL + 64;                  // float2 [16 k2][8 p1]: W_128^{p1 k2}
-#ifdef WRP_EXP_B_STAMPS   // diagnostics build (tools/fused_stamps_b.py): [16 tasks][9] 64-bit stamps behind the tables
-    static constexpr int OFF_STAMPS = OFF_TW2 + 16 * 8 * 8;
-    static constexpr int LDS_BYTES = OFF_STAMPS + FUSED_STAMP_TASKS * FUSED_STAMPS * 8;   // 80064: still two per CU
-#else
-    static constexpr int LDS_BYTES = OFF_TW2 + 16 * 8 * 8;        // 78912
-#endif
+    static constexpr int OFF_STAMPS = OFF_TW2 + 16 * 8 * 8;       // diagnostics instantiation (tools/fused_stamps_b.py): [16 tasks][9] 64-bit stamps
+    static constexpr int LDS_BYTES = OFF_STAMPS + FUSED_STAMP_TASKS * FUSED_STAMPS * 8;   // 80064: two workgroups per CU
     static constexpr int OFF_TWN = 8 * 4 * DB_ROW_ELEMS * 8;      // row workgroup: 8 waves x 4 row buffers, then exp(+2 pi i k / 128)
     static_assert(OFF_TWN + RB_N * 8 <= OFF_CTL, "row workgroup layout fits");
     static_assert(OFF_CTL == FusedTile::OFF_CTL, "the control words sit where fused_join / fused_leave expect them");
@@ -61,19 +57,10 @@ __device__ __forceinline__ void rb_derive_twiddles(cf (&tw)[16])
 // half of every 128-byte line at the same time and finds it in (or on its way into) the L2.  Non-temporal like the
 // 1024 x 512 launch's input: beside a PLAIN stream the rewritten slot does not stay in the L2 (83 % of the intermediate
 // was written back: WRITE_SIZE 1.75 MB per sector, profiles/r03/fused_b_input_policy.log).
-#ifndef WRP_FUSED_B_INPUT_AUX
-#define WRP_FUSED_B_INPUT_AUX 2   /* AUX_NT */
-#endif
-constexpr int FUSED_B_INPUT_AUX = WRP_FUSED_B_INPUT_AUX;
+constexpr int FUSED_B_INPUT_AUX = AUX_NT;
 // Request pacing (wrp_fused.h): 16 = one load at a time over the task, 1.69 us/sector, HBM traffic 1.13 x the algorithmic
 // bytes; 4 = four quarters, 1.74 us/sector, 1.06 x (the smoother stream leaves fewer non-temporal lines per L2 set to evict
 // in place of the slot's): profiles/r03/fused_b_input_policy.log, ab_request_pacing_B.log.
-#ifndef WRP_FUSED_B_SLOTS
-#define WRP_FUSED_B_SLOTS 1     // 2: one slot per half (A/B: no wait for `loaded` inside a task; 2 MiB per XCD do not stay in the L2)
-#endif
-#ifndef WRP_FUSED_B_PIECES
-#define WRP_FUSED_B_PIECES 16
-#endif
 template <int QUARTER>
 __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                   float4 (&v)[16], float2 &wdv, bool valid)
@@ -82,18 +69,7 @@ __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-unif
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int p0 = w * 16 + (l >> 2), cp = l & 3;
-#ifdef WRP_EXP_B_NOLOAD
-    valid = false;
-#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
-#ifdef WRP_EXP_B_FULLLINE   // timing only: whole 128-byte lines, the two members of a pair take alternate rows
-    const int pp = w * 8 + (l >> 3), c8 = l & 7, par = (col_base >> 3) & 1;
-    const int voffx = ((2 * pp + par) * RB_N + (col_base & ~15) + c8 * 2) * 8;
-#pragma unroll
-    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voffx, 128 * r * RB_N * 8);
-    if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
-    return;
-#endif
     const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
 #pragma unroll
     for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * r * RB_N * 8);
@@ -109,19 +85,9 @@ __device__ __forceinline__ void fused_b_tile_load1(const float2 *src /* wave-uni
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int p0 = w * 16 + (l >> 2), cp = l & 3;
-#ifdef WRP_EXP_B_NOLOAD
-    valid = false;
-#endif
-#ifdef WRP_EXP_B_DROP     // timing only: the pieces of this bit mask are not fetched (zero-record descriptor)
-    if ((WRP_EXP_B_DROP >> R) & 1) valid = false;
-#endif
     const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
     const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
-#ifdef WRP_EXP_B_HALFBYTES   // timing only: the same sixteen requests per wave, HALF the bytes each (results are wrong)
-    { const float2 h = buf_load_f2<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8); v[R] = make_float4(h.x, h.y, h.x, h.y); }
-#else
     v[R] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8);
-#endif
     if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
@@ -250,13 +216,14 @@ __device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, in
         }
 }
 
-template <int TAPS>
+template <int TAPS, bool STAMPS = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_2048x128(
     const float2 *__restrict__ iq,   // [S][C][2048][128]
     float *__restrict__ out,         // [S][1024][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS]: per team ONE slot [2 channels][512][128] through which both halves go
     FusedCtl *ctl, RangeConsts rc /* wr_c symmetric */, const float2 *__restrict__ tw_n /* exp(+2 pi i k / 128) */, int n_sectors,
-    int channels, MaTaps taps, float k_rr, float k_cal, unsigned *host_status, unsigned long long *stamps /* -DWRP_EXP_B_STAMPS builds only */)
+    int channels, MaTaps taps, float k_rr, float k_cal, unsigned *host_status, unsigned long long *stamps /* STAMPS instantiation: [grid][FUSED_STAMP_TASKS][9] */,
+    unsigned *frames /* optional (N2): [S][2][1 + 1024] words */, const unsigned *frame_hdrs /* [S] header words */)
 {
     typedef FusedTileB T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -271,22 +238,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         return;
     }
     const int tasks = (n_sectors - trank + teams - 1) / teams;   // sectors of this team: one task each
-    float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS * WRP_FUSED_B_SLOTS;
-    float2 *mid1 = mid + (WRP_FUSED_B_SLOTS - 1) * FUSED_TEAM_ELEMS;     // where half 1 goes
-#ifdef WRP_EXP_B_STAMPS
+    float2 *mid = pool + (size_t)xcc * FUSED_TEAM_ELEMS;
+    // diagnostics instantiation only: stamps go to LDS and are copied out at the end (tools/fused_stamps_b.py)
     unsigned long long *s_stamps = reinterpret_cast<unsigned long long *>(smem + T::OFF_STAMPS);
-    for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS) s_stamps[e] = 0;
-    __syncthreads();
-    if (tid == 0) s_stamps[FUSED_STAMPS - 1] = ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
-    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+    if (STAMPS) {
+        for (int e = tid; e < FUSED_STAMP_TASKS * FUSED_STAMPS; e += FUSED_THREADS) s_stamps[e] = 0;
+        __syncthreads();
+        if (tid == 0) s_stamps[FUSED_STAMPS - 1] = ((unsigned long long)kind << 32) | ((unsigned long long)xcc << 16) | (unsigned)rank;
+    }
+    const unsigned long long clk_t0 = STAMPS ? __builtin_amdgcn_s_memtime() : 0, clk_r0 = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0;
     auto stamp = [&](int q, int k) {   // wave 0 of the workgroup, slots 0 .. 7 of the task
-        if (w == 0 && q < FUSED_STAMP_TASKS) {
+        if (STAMPS && w == 0 && q < FUSED_STAMP_TASKS) {
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
             if (l == 0) s_stamps[q * FUSED_STAMPS + k] = t;
         }
     };
     auto flush_stamps = [&]() {
-        if (stamps) {
+        if (STAMPS && stamps) {
             if (tid == 0) {
                 s_stamps[1 * FUSED_STAMPS + FUSED_STAMPS - 1] = __builtin_amdgcn_s_memtime() - clk_t0;
                 s_stamps[2 * FUSED_STAMPS + FUSED_STAMPS - 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -296,19 +264,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 stamps[(size_t)blockIdx.x * FUSED_STAMP_TASKS * FUSED_STAMPS + e] = s_stamps[e];
         }
     };
-#else
-    auto stamp = [](int, int) {};
-    auto flush_stamps = []() {};
-#endif
 
     if (kind == 0) {
         // =============================== tile member: channel rank >> 4, 8-column tile rank & 15 ===============================
         const int ch = rank >> 4, col_base = (rank & 15) * 8;
-#ifdef WRP_EXP_B_SAMESECTOR   // timing only: every task reads the team's FIRST sector again (Infinity Cache / L2 hits, real data)
-        auto tile_src = [&](int q) { return iq + ((size_t)(trank + 0 * q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
-#else
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
-#endif
         float4 v[16];
         float2 wdv;
         fused_b_tile_load<0>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
@@ -349,27 +309,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             const bool more = q + 1 < tasks;
             cf o[2][4];
 #define WRP_LB(R) fused_b_tile_load1<R>(next, col_base, rc.wd, v, wdv, more)
-#if WRP_FUSED_B_PIECES == 4
-            WRP_LB(0); WRP_LB(4); WRP_LB(8); WRP_LB(12);
-            fused_b_stage2(smem);
-            WRP_LB(1); WRP_LB(5); WRP_LB(9); WRP_LB(13);
-            fused_b_stage3(smem, o);
-#else
             WRP_LB(0); WRP_LB(8);
             fused_b_stage2(smem);
             WRP_LB(4); WRP_LB(12);
             fused_b_stage3(smem, o);
             WRP_LB(1); WRP_LB(9);
-#endif
-            spin_flags_sticky(WRP_FUSED_B_SLOTS == 2 ? my_loaded0 : my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1 (two slots: half 0 of task q - 1)
+            spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
             fused_b_store(mid, ch, col_base, o);
             __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
-#if WRP_FUSED_B_PIECES == 4
-            WRP_LB(2); WRP_LB(6); WRP_LB(10); WRP_LB(14);
-#else
             WRP_LB(5); WRP_LB(13); WRP_LB(2); WRP_LB(10);
-#endif
             fused_b_group1_to_lds(smem, ga, gc);
             stamp(q, 2);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
@@ -379,23 +328,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
             __syncthreads();                    // A3: group 1 is in the image
             stamp(q, 3);
-#if WRP_FUSED_B_PIECES == 4
-            fused_b_stage2(smem);
-            WRP_LB(3); WRP_LB(7); WRP_LB(11); WRP_LB(15);
-            fused_b_stage3(smem, o);
-#else
             WRP_LB(6);
             fused_b_stage2(smem);      // (its sixteen points + fifteen twiddles need registers: most of the rest is requested behind it)
             WRP_LB(14); WRP_LB(3);
             fused_b_stage3(smem, o);
             WRP_LB(11); WRP_LB(7); WRP_LB(15);
-#endif
 #undef WRP_LB
             stamp(q, 7);
-            spin_flags_sticky(WRP_FUSED_B_SLOTS == 2 ? my_loaded1 : my_loaded0, (unsigned)(WRP_FUSED_B_SLOTS == 2 ? q : q + 1), failed, w != 0);
+            spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             stamp(q, 4);
             __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
-            fused_b_store(mid1, ch, col_base, o);
+            fused_b_store(mid, ch, col_base, o);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -413,13 +356,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         __syncthreads();
         const int sub = l >> 4, i = l & 15, pb = sub & 1, chn = sub >> 1;
         float2 *rbuf = reinterpret_cast<float2 *>(smem) + (size_t)(w * 4 + sub) * DB_ROW_ELEMS;
-        const rsrc_t rs0 = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u), rs1 = make_rsrc(mid1, (unsigned)FUSED_TEAM_ELEMS * 8u);
+        const rsrc_t rs = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
         const int Q = 8 * rank + w;
         const int voff = (chn * 256 + Q) * 2048 + (i >> 3) * 128 + pb * 64 + (i & 7) * 8;   // element j = i + 16 r: tile 2 r + (i >> 3)
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             bool there = true;
-            float *o2 = &out[(size_t)(trank + q * teams) * gates * 2];
+            const int sec = trank + q * teams;
+            float *o2 = &out[(size_t)sec * gates * 2];
+            unsigned *fr = frames ? frames + (size_t)sec * 2 * (1 + gates) : nullptr;
 #pragma unroll
             for (int g = 0; g < 2; g++) {
                 stamp(q, 4 * g);
@@ -429,7 +374,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 __builtin_amdgcn_s_setprio(FUSED_ROW_PRIO);     // the notice-to-`loaded` stretch at raised priority: wrp_fused.h
                 cf x[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_SC1>(g ? rs1 : rs0, voff, r * 256);
+                for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_SC1>(rs, voff, r * 256);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows in registers: the slot may be overwritten
                 int last = 0;
                 if (l == 0) last = atomicAdd(reinterpret_cast<int *>(smem + T::OFF_CTL + 48 + 4 * g), 1) == 8 * q + 7;
@@ -437,13 +382,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 __builtin_amdgcn_s_setprio(0);
                 stamp(q, 4 * g + 2);
                 const int gate = fused_b_gate(g, Q, pb);
-#ifdef WRP_EXP_B_NOROW
-                const float S = x[0].x + x[7].y;
-#else
                 const float S = doppler_row_128<TAPS>(x, rbuf, s_twn, taps, i);
-#endif
                 const float other = __shfl(S, (l + 32) & 63);     // the VV row sum sits 32 lanes above the HH one
-                if (i == 0 && chn == 0) reflectivity_store(o2 + 2 * gate, gate, S, other, k_rr, k_cal);
+                if (i == 0 && chn == 0) reflectivity_store(o2 + 2 * gate, gate, S, other, k_rr, k_cal, fr, gates, fr ? frame_hdrs[sec] : 0u);
                 stamp(q, 4 * g + 3);
             }
             if (!there) break;

@@ -113,8 +113,11 @@ __global__ __launch_bounds__(64) void generic_doppler_pass(
         if (do_dump && dump.rowsum && l == 0) dump.rowsum[gate] = S[ch];
         wave_lds_fence();
     }
-    if (l == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, sec == 0 ? dump.frames : nullptr, gates);
-    frame_headers(dump, gates, threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0);
+    if (l == 0) {
+        unsigned hdr;
+        unsigned *frames = sector_frames(dump, sec, gates, hdr);
+        reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, frames, gates, hdr);
+    }
 }
 
 } // namespace wrp

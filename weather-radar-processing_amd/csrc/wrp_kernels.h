@@ -29,11 +29,26 @@ struct DumpPtrs {       // all optional (nullptr = skip); one sector, one channe
     float *pow;         // [m/2][n]
     float *rowsum;      // [m/2]
     int channel;        // which channel the dump refers to
-    // not a dump: the products of sector 0 of the launch framed for the wire -- two planes of 1 + m/2 words,
-    // [header][m/2 BIG-ENDIAN floats], Zdb then Zdr (rpv2.cu:631-661 does the swap on the CPU, aftoab); nullptr = none
+    // not a dump: the products framed for the wire -- per sector two planes of 1 + m/2 words,
+    // [header][m/2 BIG-ENDIAN floats], Zdb then Zdr (rpv2.cu:631-661 does the swap on the CPU, aftoab); nullptr = none.
+    // frame_hdrs == nullptr: sector 0 of the launch only, header frame_hdr (the slot path); otherwise every sector s of the
+    // launch, frames + s * 2 * (1 + m/2), header frame_hdrs[s] (the batch entries)
     unsigned *frames;
     unsigned frame_hdr; // the header word as it lies in memory: sector BE16, elevation BE16
+    const unsigned *frame_hdrs;
 };
+// where the frames of sector `sec` of the launch go (nullptr: nowhere) and their header word
+__device__ __forceinline__ unsigned *sector_frames(const DumpPtrs &d, int sec, int gates, unsigned &hdr)
+{
+    hdr = d.frame_hdr;
+    if (!d.frames) return nullptr;
+    if (!d.frame_hdrs) return sec == 0 ? d.frames : nullptr;
+    hdr = d.frame_hdrs[sec];
+    return d.frames + (size_t)sec * 2 * (1 + gates);
+}
+// a batch launch that only runs when the fused launch in front of it on the stream has given up: *gate is that launch's
+// status word in device memory (0 = it succeeded, there is nothing to repeat); nullptr = not gated
+__device__ __forceinline__ bool gate_closed(const unsigned *gate /* wave-uniform */) { return gate && *gate == 0; }
 
 struct MaTaps { float g[9]; };
 
@@ -292,9 +307,10 @@ template <int TCOLS, bool DUMP>
 __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
     const float2 *__restrict__ iq,   // [S][C][1024][n]
     float2 *__restrict__ mid,        // [S][2][512][n]
-    RangeConsts rc, int n, int channels, DumpPtrs dump)
+    RangeConsts rc, int n, int channels, DumpPtrs dump, const unsigned *gate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate_closed(gate)) return;
     const int tiles = n / TCOLS;
     int b = blockIdx.x;
     if (TCOLS == 8) {
@@ -326,9 +342,11 @@ __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024(
 // waiting for its loads and computing).  Same device functions -> bit-identical results.
 template <int TCOLS>
 __global__ __launch_bounds__(RangeTile<TCOLS>::THREADS) void range_pass_1024_persistent(
-    const float2 *__restrict__ iq, float2 *__restrict__ mid, RangeConsts rc, int n, int channels, int total_tiles)
+    const float2 *__restrict__ iq, float2 *__restrict__ mid, RangeConsts rc, int n, int channels, int total_tiles,
+    const unsigned *gate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate_closed(gate)) return;
     const int tiles = n / TCOLS;
     const DumpPtrs nodump{};
     auto decode = [&](int b, int &tile, int &ch, int &sec) {
@@ -375,14 +393,10 @@ constexpr int DP_WAVES = 4;
 constexpr int DP_ELEMS = DP_N + DP_N / 8;   // padded complex elements per wave buffer (576 = 4608 B)
 
 // element index of position p: two elements of padding per 16 (tools/lds_banks.py: stage 1's and stage 2's accesses
-// conflict free, stage 3's reads two passes: 112 LDS cycles per row for the three exchanges; with neighbours swapped
-// where bit 3 of the position is set -- WRP_DP_SWIZZLE -- 96, the ideal)
-#ifndef WRP_DP_SWIZZLE
-#define WRP_DP_SWIZZLE 0    // 1: neighbouring elements swapped where bit 3 of the position is set: stage-3 reads conflict-free too
-                            // (SQ_LDS_BANK_CONFLICT 9.7 M -> 3.8 M per launch), eight 8-byte reads instead of four 16-byte ones and a
-                            // second address register: bit-identical, +0.2 % -- not adopted (profiles/r03/ab_doppler_lds_swizzle.log)
-#endif
-__device__ __forceinline__ int dp_idx(int pos) { return (WRP_DP_SWIZZLE ? pos ^ ((pos >> 3) & 1) : pos) + 2 * (pos >> 4); }
+// conflict free, stage 3's reads two passes: 112 LDS cycles per row for the three exchanges.  With neighbours swapped where
+// bit 3 of the position is set all three are conflict free (96 cycles) and the launch is no faster:
+// profiles/r03/ab_doppler_lds_swizzle.log; not kept)
+__device__ __forceinline__ int dp_idx(int pos) { return pos + 2 * (pos >> 4); }
 // float index of |.|^2 bin j: 4 floats of padding per 8 -> b32 writes and b128 reads conflict free
 __device__ __forceinline__ int dp_fidx(int j) { return j + 4 * (j >> 3); }
 
@@ -488,10 +502,8 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
     // dp_idx(pos) = pos + 2 (pos >> 4) is linear in the unrolled counter (one address register per stage, immediates
     // for the eight elements), which the compiler does not find by itself:
     //   dp_idx(k1 64 + l)            = dp_idx(l) + 72 k1
-    //   dp_idx(k1 64 + p1 + 8 r)     = 72 k1 + (p1 ^ (r & 1)) + 8 r + 2 (r >> 1)
-    //   dp_idx(k1 64 + 8 k2 + r)     = 72 k1 + 8 k2 + 2 (k2 >> 1) + (r ^ (k2 & 1))
-    // (the terms in p1 ^ .. and r ^ .. only with WRP_DP_SWIZZLE: a second address register in stages 2 and 3, for the even and
-    // the odd elements of the unrolled counter)
+    //   dp_idx(k1 64 + p1 + 8 r)     = 72 k1 + p1 + 8 r + 2 (r >> 1)
+    //   dp_idx(k1 64 + 8 k2 + r)     = 72 k1 + 8 k2 + 2 (k2 >> 1) + r
     fft8<+1>(v);                                   // stage 1: lane l owns j = l + 64 r
     const int b1 = dp_idx(l);
     buf[b1] = v[0];
@@ -499,22 +511,21 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
     for (int k1 = 1; k1 < 8; k1++) buf[b1 + 72 * k1] = cmul(v[k1], t1[k1]);
     wave_lds_fence();
     {                                              // stage 2: lane = p1 + 8 k1, positions k1*64 + p1 + 8 r
-        const int b2 = 72 * (l >> 3) + (l & 7), b2o = 72 * (l >> 3) + ((l & 7) ^ (WRP_DP_SWIZZLE ? 1 : 0));   // even / odd r
+        const int b2 = 72 * (l >> 3) + (l & 7);
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = buf[(r & 1 ? b2o : b2) + 8 * r + 2 * (r >> 1)];
+        for (int r = 0; r < 8; r++) v[r] = buf[b2 + 8 * r + 2 * (r >> 1)];
         fft8<+1>(v);
         buf[b2] = v[0];
 #pragma unroll
-        for (int k2 = 1; k2 < 8; k2++) buf[(k2 & 1 ? b2o : b2) + 8 * k2 + 2 * (k2 >> 1)] = cmul(v[k2], t2[k2]);
+        for (int k2 = 1; k2 < 8; k2++) buf[b2 + 8 * k2 + 2 * (k2 >> 1)] = cmul(v[k2], t2[k2]);
     }
     wave_lds_fence();
     // stage 3: lane = k2 + 8 k1 owns positions k1*64 + k2*8 + r; output k = k1 + 8 k2 + 64 k3
     const int k2 = l & 7, k1 = l >> 3;
     const int klo = k1 + 8 * k2;
     const int b3 = 72 * k1 + 8 * k2 + 2 * (k2 >> 1);
-    const int b3e = b3 + (WRP_DP_SWIZZLE ? k2 & 1 : 0), b3o = b3 - (WRP_DP_SWIZZLE ? k2 & 1 : 0);   // element r sits at r ^ (k2 & 1)
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = buf[(r & 1 ? b3o : b3e) + r];
+    for (int r = 0; r < 8; r++) v[r] = buf[b3 + r];
     fft8<+1>(v);
     wave_lds_fence();   // everyone has read before the buffer is reused for |.|^2
 
@@ -566,7 +577,7 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
 
 // a9: reflectivity (rpv2.cu:199-213): z = (gate*k_rr)^2 * k_cal * S_hh in double, rounded once
 __device__ __forceinline__ void reflectivity_store(float *out2, int gate, float s_hh, float s_vv, float k_rr, float k_cal,
-                                                   unsigned *frames = nullptr, int gates = 0)
+                                                   unsigned *frames = nullptr, int gates = 0, unsigned hdr = 0)
 {
     const double rng = (double)gate * (double)k_rr;
     const float z = (float)(rng * rng * (double)k_cal * (double)s_hh);
@@ -576,14 +587,10 @@ __device__ __forceinline__ void reflectivity_store(float *out2, int gate, float 
     if (frames) {   // wire-ready: the same bits, big-endian, planar (read_single.cc:510-520, rpv2.cu:631-661)
         frames[1 + gate] = __builtin_bswap32(__builtin_bit_cast(unsigned, zdb));
         frames[1 + gates + 1 + gate] = __builtin_bswap32(__builtin_bit_cast(unsigned, zdr));
-    }
-}
-// the header words of the two frames (one thread of the launch)
-__device__ __forceinline__ void frame_headers(const DumpPtrs &dump, int gates, bool first_thread)
-{
-    if (dump.frames && first_thread) {
-        dump.frames[0] = dump.frame_hdr;
-        dump.frames[1 + gates] = dump.frame_hdr;
+        if (gate == 0) {   // the header words of the two frames travel with gate 0
+            frames[0] = hdr;
+            frames[1 + gates] = hdr;
+        }
     }
 }
 
@@ -592,10 +599,11 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
     const float2 *__restrict__ mid,  // [S][2][gates][512]
     float *__restrict__ out,         // [S][gates][2]
     const float2 *__restrict__ tw,   // [DP_TW_ELEMS] exp(+2 pi i k / 512), arranged (doppler_twiddle_index)
-    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump)
+    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump, const unsigned *gate_word)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DP_WAVES][DP_ELEMS];
     __shared__ __attribute__((aligned(16))) float2 s_tw[DP_TW_ELEMS];
+    if (gate_closed(gate_word)) return;
     const int w = wave_id(), l = threadIdx.x & 63;
     const int gate = blockIdx.x * DP_WAVES + w;
     const int sec = blockIdx.y;
@@ -609,8 +617,11 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 #pragma unroll
     for (int ch = 0; ch < 2; ch++)
         S[ch] = doppler_row<DUMP, TAPS>(x[ch], lds[w], s_tw, taps, l, gate, DUMP && dump.channel == ch && sec == 0, dump);
-    if (l == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, sec == 0 ? dump.frames : nullptr, gates);
-    frame_headers(dump, gates, threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0);
+    if (l == 0) {
+        unsigned hdr;
+        unsigned *frames = sector_frames(dump, sec, gates, hdr);
+        reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, frames, gates, hdr);
+    }
 }
 
 // =============================================================================================
@@ -622,10 +633,10 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 // =============================================================================================
 __global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [sectors = gridDim.y][count][3] dwords
                                                     float2 *__restrict__ iq,            // [sectors][channels][count]
-                                                    int count, int channels)
+                                                    int count, int channels, const unsigned *gate)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= count) return;
+    if (t >= count || gate_closed(gate)) return;
     raw += (size_t)blockIdx.y * count * 3;
     iq += (size_t)blockIdx.y * channels * count;
     const unsigned w0 = raw[3 * t], w1 = raw[3 * t + 1], w2 = raw[3 * t + 2];

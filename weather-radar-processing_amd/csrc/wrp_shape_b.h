@@ -155,10 +155,11 @@ __device__ __forceinline__ void rb_stage3_store(unsigned char *smem, float2 *dst
 __global__ __launch_bounds__(RangeTileB::THREADS, 4) void range_pass_2048(
     const float2 *__restrict__ iq,   // [S][C][2048][128]
     float2 *__restrict__ mid,        // [S][2][1024][128]
-    RangeConsts rc, int channels, int total_tiles)
+    RangeConsts rc, int channels, int total_tiles, const unsigned *gate)
 {
     typedef RangeTileB T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate_closed(gate)) return;
     constexpr int tiles = RB_N / 16;
     auto decode = [&](int b, int &tile, int &ch, int &sec) {
         tile = b % tiles; b /= tiles;
@@ -335,10 +336,11 @@ __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     const float2 *__restrict__ mid,  // [S][2][gates][128]
     float *__restrict__ out,         // [S][gates][2]
     const float2 *__restrict__ tw,   // [128] exp(+2 pi i k / 128)
-    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump = DumpPtrs{})
+    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump, const unsigned *gate_word)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DB_WAVES * 4][DB_ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) float2 s_tw[RB_N];
+    if (gate_closed(gate_word)) return;
     const int w = wave_id(), l = threadIdx.x & 63;
     const int sub = l >> 4, i = l & 15;               // sub: 0 (g, HH), 1 (g, VV), 2 (g + 1, HH), 3 (g + 1, VV)
     const int gate = (blockIdx.x * DB_WAVES + w) * 2 + (sub >> 1), ch = sub & 1;
@@ -353,8 +355,11 @@ __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     __syncthreads();
     const float S = doppler_row_128<TAPS, DUMP>(x, lds[w * 4 + sub], s_tw, taps, i, gate, DUMP && dump.channel == ch && sec == 0, dump);
     const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
-    if (i == 0 && ch == 0) reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal, sec == 0 ? dump.frames : nullptr, gates);
-    frame_headers(dump, gates, threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0);
+    if (i == 0 && ch == 0) {
+        unsigned hdr;
+        unsigned *frames = sector_frames(dump, sec, gates, hdr);
+        reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal, frames, gates, hdr);
+    }
 }
 
 } // namespace wrp

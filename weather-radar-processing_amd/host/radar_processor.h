@@ -12,6 +12,7 @@
 #define WRP_HOST_RADAR_PROCESSOR_H
 #include <stddef.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -34,7 +35,7 @@ struct SectorTurnstile {
     std::condition_variable cv;
     long next = 0;        // global sequence number (elevation * n_sectors + sector) of the sector to be read next
     bool reading = false; // a processor is inside the (blocking) source call -- made WITHOUT the mutex held
-    bool ended = false;   // the source is exhausted (or failed): nobody reads any more
+    std::atomic<bool> ended{false};   // the source is exhausted (or failed): nobody reads any more (written under mu; rpv2.cpp's UDP retry loop reads it without)
     std::mutex sink_mu;   // frames of different GPUs leave through one sink, one frame at a time
 };
 
