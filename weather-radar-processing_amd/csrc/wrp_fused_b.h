@@ -267,14 +267,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
 
     if (kind == 0) {
         // =============================== tile member: channel rank >> 4, 8-column tile rank & 15 ===============================
-        const int ch = rank >> 4, col_base = (rank & 15) * 8;
+        const int ch = rank >> 4;
+        // the member's 8-column tile of task q: rotated by TWO from task to task (the pair t, t ^ 1 keeps asking for the two
+        // halves of the same lines), so that a tile that loads slowly is a transient of every member instead of one member
+        // that is late in every task (wrp_fused.h: tile_col)
+        auto tile_col = [&](int q) { return (((rank & 15) + 2 * q) & 15) * 8; };
         auto tile_src = [&](int q) { return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
         float4 v[16];
         float2 wdv;
-        fused_b_tile_load<0>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
-        fused_b_tile_load<1>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
-        fused_b_tile_load<2>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
-        fused_b_tile_load<3>(tile_src(0), col_base, rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<0>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<1>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<2>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<3>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
         for (int e = tid; e < RB_M / 2; e += FUSED_THREADS) {
             const int p0 = e >> 3, j = e & 7;
             *reinterpret_cast<float2 *>(smem + T::tw1_addr(p0, j)) = rc.tw[(p0 * (j + 1)) & (RB_M - 1)];
@@ -307,8 +311,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             stamp(q, 1);
             const float2 *next = tile_src(q + 1 < tasks ? q + 1 : 0);
             const bool more = q + 1 < tasks;
+            const int col_base = tile_col(q), next_col = tile_col(q + 1);
             cf o[2][4];
-#define WRP_LB(R) fused_b_tile_load1<R>(next, col_base, rc.wd, v, wdv, more)
+#define WRP_LB(R) fused_b_tile_load1<R>(next, next_col, rc.wd, v, wdv, more)
             WRP_LB(0); WRP_LB(8);
             fused_b_stage2(smem);
             WRP_LB(4); WRP_LB(12);
