@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase anatomy of the fused 2048 x 128 launch; needs a library built with -DWRP_EXP_B_STAMPS (WRP_LIB_PATH=...).
+"""Phase anatomy of the fused 2048 x 128 launch (its STAMPS instantiation, through wrp_debug_fused_stamps).
 Wave 0 of every workgroup stamps its first 16 tasks (s_memrealtime, 100 MHz); slot 8 of task 0 = kind << 32 | xcc << 16 | rank.
   tile: 0 task start, 5 column 0 of stage 1 done (the first use of the tile: includes the wait for its last pieces), 1 A1,
         2 stages 2-3 of group 0 + look A + A2 + stores + group 1 written, 6 stores drained (vmcnt), 3 A3,
@@ -40,7 +40,7 @@ def main():
         rc = eng.lib.wrp_debug_fused_stamps(eng.handle, C.c_void_p(d_iq.data_ptr()), S, C.c_void_p(d_out.data_ptr()),
                                             st.ctypes.data_as(C.c_void_p), st.size)
         assert rc == 0, (rc, eng.lib.wrp_last_hip_error(eng.handle))
-    assert st[:, 0, 8].any(), "no stamps: the library was not built with -DWRP_EXP_B_STAMPS"
+    assert st[:, 0, 8].any(), "no stamps came back"
     ident = st[:, 0, 8]
     kind = (ident >> np.uint64(32)).astype(int)
     clk = st[:, 1, 8].astype(np.float64) / np.maximum(st[:, 2, 8].astype(np.float64), 1.0) * 100.0

@@ -2,9 +2,9 @@
 # Everything profiles/rNN/ holds, from ONE box and ONE build: bench lines (shape A default command, shape B),
 # rocprofv3 --kernel-trace --stats of the same commands, the PMC passes (tools/profile_pmc.sh) and the
 # traffic.json bench.py reads (fingerprint of the sources it was measured on).  Copy gpurun_out/rNN/ to profiles/rNN/.
-# usage: tools/profile_round.sh r02
+# usage: tools/profile_round.sh r04
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/$R; mkdir -p $OUT
 echo "== bench A (default command)"; python3 bench.py > $OUT/bench_A_first.json 2> $OUT/bench_A_first.err; tail -c 400 $OUT/bench_A_first.json

@@ -302,7 +302,9 @@ int main(int argc, char **argv)
     using namespace wrp;
     int tiles = 192;
     bool do_check = true;
+    const char *only = nullptr;      // --only SUBSTRING: time the variants whose line contains it (PMC passes)
     for (int a = 1; a < argc; a++) {
+        if (!strcmp(argv[a], "--only") && a + 1 < argc) only = argv[++a];
         if (!strcmp(argv[a], "--tiles") && a + 1 < argc) tiles = atoi(argv[++a]);
         if (!strcmp(argv[a], "--no-check")) do_check = false;
     }
@@ -397,6 +399,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto time_it = [&](const char *what, auto launch, int wgs_per_cu) {
+        if (only && !strstr(what, only)) return;
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             CK(hipEventRecord(e0));

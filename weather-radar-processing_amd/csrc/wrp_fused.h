@@ -714,8 +714,19 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
     if (failed && l == 0) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// target("no-load-store-opt"): hipcc's load / store optimiser merges neighbouring LDS accesses into ds_read2_b64 /
+// ds_write2_b64 (one address register, two offsets).  On gfx950 a ds_read2_b64 is served in 16-lane groups and takes 7.9 LDS
+// cycles where two ds_read_b64 (32-lane groups) take 4.6 (tools/ldsopbench.hip, profiles/r04/ldsopbench.log): the tile and row
+// stages read 51 + 10 such pairs per wave and task.  Without the pass: bit-identical, 123 instead of 128 VGPRs, -1.6 %
+// (wire format -3.5 %, 4 instead of 6 spilled registers; profiles/r04/ab_no_ds_read2.log).  The 2048 x 128 launch keeps the
+// pass (+2.3 % without it).
+#if defined(__HIP_DEVICE_COMPILE__)       // (a code-generation attribute of the gfx950 pass; the host pass does not know it)
+#define WRP_NO_DS_MERGE __attribute__((target("no-load-store-opt")))
+#else
+#define WRP_NO_DS_MERGE
+#endif
 template <int TAPS, bool STAMPS, bool RAW = false>
-__global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_1024x512(
+__global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) WRP_NO_DS_MERGE void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]; RAW: the wire format, [S][1024 x 512][12 bytes]
     float *__restrict__ out,         // [S][512][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
