@@ -242,15 +242,17 @@ def _check_frames(oracle, frames, out, ids, gates):
     assert frames.shape[2] == fw
 
 
-@pytest.mark.parametrize("shape", ["A", "B"])
+@pytest.mark.parametrize("shape", ["A", "B", "generic"])
 def test_batch_entries_frame_their_products_for_the_wire(wrp, oracle, sectors, sectors_b, shape):
     """SURVEY 8f N2 for batches: wrp_process_batch_framed_device / _raw_framed_device write, beside d_out, both products of
     every sector as [header word][m/2 BIG-ENDIAN floats] -- byte-exact against the oracle's framing of the same results
     (rpv2.cu:631-661) for every launch form: fused, wire-format fused, the two kernels (a small batch, the flag), a fused
-    launch that gave up and was repeated (engine stream: by wrp_check; caller stream: by the gated launches)."""
+    launch that gave up and was repeated (engine stream: by wrp_check; caller stream: by the gated launches); and for a shape
+    without a fused kernel (256 x 64: the shape-generic kernels)."""
     import torch
-    m, n = (2048, 128) if shape == "B" else (M, N)
-    pool = sectors_b if shape == "B" else sectors
+    m, n = {"A": (M, N), "B": (2048, 128), "generic": (256, 64)}[shape]
+    pool = sectors_b if shape == "B" else sectors if shape == "A" else [oracle.synthetic_sector(20 + s, m, n) for s in range(3)]
+    fused_shape = shape != "generic"
     gates = m // 2
     count = 11
     batch = np.stack([_variant(pool, 2 * k + 1) for k in range(count)])
@@ -282,6 +284,6 @@ def test_batch_entries_frame_their_products_for_the_wire(wrp, oracle, sectors, s
             e.check()
             assert np.array_equal(out.view(np.uint32), want[:n_sec].view(np.uint32)), (flags, n_sec, raw)
             _check_frames(oracle, frames, out, ids[:n_sec], gates)
-            assert e.fused_fallbacks == (1 if flags == wrp.FLAG_DEBUG_FUSED_UNDERSIZED else 0)
+            assert e.fused_fallbacks == (1 if flags == wrp.FLAG_DEBUG_FUSED_UNDERSIZED and fused_shape else 0)
     with wrp.Engine(device=0, m=m, n=n, n_slots=1) as e:
         assert e.lib.wrp_process_batch_framed_device(e.handle, d_in.data_ptr(), count, d_out.data_ptr(), None, None, None) == -1
