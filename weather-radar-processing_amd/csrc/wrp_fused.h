@@ -535,7 +535,8 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
 // ITEMS (the planar mapping's are two columns at one p0).  ONE set of 64 registers feeds BOTH channel-tasks of the sector,
 // VH is never fetched into a register, byte swap + conversion cost three instructions per sample and channel in stage 1.
 // HBM: 6 MiB per sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
-// ONE piece of the wire-format tile: the rows pq + 64 RR and pq + 32 + 64 RR (sixteen pieces, requested one at a time)
+// ONE piece of the wire-format tile: the rows pq + 64 RR and pq + 32 + 64 RR (sixteen pieces, requested one at a time:
+// eight in each of the sector's two tasks)
 template <int RR>
 __device__ __forceinline__ void fused_raw_tile_load1(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
                                                      float2 (&v)[32], float &wdv, bool valid)
@@ -575,10 +576,11 @@ __device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /
     }
 }
 
-// stage 1 of ITEM (0: position pq, 1: pq + 32) of the lane's column for channel CH; the twiddles are read behind the
-// butterfly in two batches of eight (the registers still hold the other channel's dwords: no room for fifteen)
-template <int ITEM, int CH>
-__device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const float2 (&v)[32], float wdv, cf (&g)[8])
+// stage 1 of ITEM (0: position pq, 1: pq + 32) of the lane's column; s[r] = the channel's dword of row pq + 32 r.  The
+// twiddles are read behind the butterfly in two batches of eight (the registers hold the other channel's dwords or the
+// next sector's first pieces: no room for fifteen)
+template <int ITEM>
+__device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const float (&s)[32], float wdv, cf (&g)[8])
 {
     typedef FusedTile T;
     int tid = threadIdx.x;
@@ -594,7 +596,7 @@ __device__ __forceinline__ void fused_stage1_raw(unsigned char *smem, const floa
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         wgt[r] = s_wr[p0 + 64 * r];
-        a[r] = wire_sample(CH ? v[2 * r + ITEM].y : v[2 * r + ITEM].x);
+        a[r] = wire_sample(s[2 * r + ITEM]);
     }
     fft16_scaled<-1>(a, wgt, wdv);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
@@ -625,8 +627,15 @@ __device__ __forceinline__ void fused_raw_group1_to_lds(unsigned char *smem, con
 }
 
 // The tile member of the wire-format launch: the loop of fused_chain_1024x512's tile member with the two channel-tasks of
-// a sector unrolled -- task HH (no requests: the registers still hold the sector's VV dwords) and task VV (behind its stage
-// 1 the next sector's tile is requested in quarters, eight loads each).  Same hand-over protocol, same sequence numbers.
+// a sector unrolled.  Same hand-over protocol, same sequence numbers.  The next sector's sixteen pieces are requested EIGHT
+// PER TASK: task HH's stage 1 leaves the HH half of every landing pair dead, but an 8-byte load needs a whole pair -- so
+// behind that stage the VV dwords are MOVED out of the pairs (32 v_mov per lane and sector), the pairs of the pieces
+// 0 .. 7 are free for the rest of task HH, and task VV, whose stage 1 reads the moved dwords, requests the pieces 8 .. 15.
+// Round 3 requested all sixteen in task VV (twice the planar launch's request rate while it lasted, none in task HH):
+// 2.49 -> 2.17 us/sector, -12.7 % (profiles/r04/ab_wire_requests_in_both_tasks.log), no spilled register (4 before).
+// The moves are written as instructions: left to the register allocator (`vv[r] = v[r].y`, it inserts the same 32
+// copies) the launch is 1.3 % slower.  Eight pieces on the points 0 1 2 3 | 5 | 6 7 9 of a task's eleven; seven other
+// placements +0.0 ... +5.5 % (ab_wire_request_schedules.log).
 __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const unsigned *raw, float2 *mid, FusedCtl *ctl,
                                                       const RangeConsts &rc, int xcc, int rank, int teams, int trank, int tasks)
 {
@@ -636,7 +645,8 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
     auto tile_col = [&](int sec) { return ((rank + sec) & (FUSED_MEMBERS - 1)) * 16; };
     auto sector_src = [&](int sec) { return raw + (size_t)(trank + sec * teams) * RP_M * DP_N * 3; };
     const int sectors = tasks >> 1;
-    float2 v[32];
+    float2 v[32];     // the landing pairs: (hh, vv) dwords of the rows pq + 32 r
+    float vv[32];     // the VV dwords of the sector in work, moved out of the pairs behind task HH's stage 1
     float wdv;
     fused_raw_tile_load<0>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
     fused_raw_tile_load<1>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
@@ -654,49 +664,60 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
     __syncthreads();
     const FusedFlags *my_loaded0 = &ctl->loaded[0][xcc][rank], *my_loaded1 = &ctl->loaded[1][xcc][rank];
     int failed = 0;
-    // one channel-task; CH = 1 also requests the next sector's tile (valid = false behind the last sector)
-    auto task = [&](auto chc, int q, int col, const unsigned *next, int next_col, bool more) {
-        constexpr int CH = decltype(chc)::value;
-        cf ga[8], gc[8];
-        fused_stage1_raw<0, CH>(smem, v, wdv, ga);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // half 1 of the previous task: drained, counted by the last wave
+    // half 1 of the previous task: drained, counted by the last wave (between the two items of stage 1, as in the planar launch)
+    auto drained = [&](int q) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int last = 0;
         if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
         if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
-        fused_stage1_raw<1, CH>(smem, v, wdv, gc);
+    };
+    // one channel-task; it requests eight of the next sector's sixteen pieces (valid = false behind the last sector)
+    auto task = [&](auto chc, int q, int col, const unsigned *next, int next_col, bool more) {
+        constexpr int CH = decltype(chc)::value;
+        cf ga[8], gc[8];
+        if (CH == 0) {
+            float hh[32];
+#pragma unroll
+            for (int r = 0; r < 32; r++) hh[r] = v[r].x;
+            fused_stage1_raw<0>(smem, hh, wdv, ga);
+            drained(q);
+            fused_stage1_raw<1>(smem, hh, wdv, gc);
+#pragma unroll
+            for (int r = 0; r < 32; r++) asm volatile("v_mov_b32 %0, %1" : "=v"(vv[r]) : "v"(v[r].y));
+        } else {
+            fused_stage1_raw<0>(smem, vv, wdv, ga);
+            drained(q);
+            fused_stage1_raw<1>(smem, vv, wdv, gc);
+        }
         __syncthreads();                    // A1
         cf o[2][4];
-#define WRP_LR(RR) if (CH) fused_raw_tile_load1<RR>(next, next_col, rc.wd, v, wdv, more)
-        WRP_LR(0); WRP_LR(8);
+#define WRP_LR(K) fused_raw_tile_load1<8 * CH + (K)>(next, next_col, rc.wd, v, wdv, more)
+        WRP_LR(0);
         fused_stage2_item<0, false>(smem);
         WRP_LR(4);
         fused_stage2_item<1, false>(smem);
-        WRP_LR(12);
+        WRP_LR(2);
         fused_stage3_item<0, false>(smem, o);
-        WRP_LR(1);
+        WRP_LR(6);
         fused_stage3_item<1, false>(smem, o);
-        WRP_LR(9);
         spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
         __syncthreads();                    // A2
         fused_store(mid, col, 0, o);
         __builtin_amdgcn_sched_barrier(0);
-        WRP_LR(5); WRP_LR(13); WRP_LR(2); WRP_LR(10);
+        WRP_LR(1);
         fused_raw_group1_to_lds(smem, ga, gc);
-        if (CH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 requests just issued: the stores are in the L2
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = 0;
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // all but the 2 requests just issued: the stores are in the L2
+        int last = 0;
         if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
         if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[0][xcc], l, rank, (unsigned)(q + 1));
         __syncthreads();                    // A3
-        WRP_LR(6);
+        WRP_LR(5);
         fused_stage2_item<0, false>(smem);
-        WRP_LR(14);
-        fused_stage2_item<1, false>(smem);
         WRP_LR(3);
+        fused_stage2_item<1, false>(smem);
         fused_stage3_item<0, false>(smem, o);
-        WRP_LR(11);
+        WRP_LR(7);
         fused_stage3_item<1, false>(smem, o);
-        WRP_LR(7); WRP_LR(15);
 #undef WRP_LR
         spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
         __syncthreads();                    // A4
@@ -705,8 +726,9 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
 #pragma unroll 1
     for (int sec = 0; sec < sectors; sec++) {
         const bool more = sec + 1 < sectors;
-        task(std::integral_constant<int, 0>{}, 2 * sec, tile_col(sec), nullptr, 0, false);
-        task(std::integral_constant<int, 1>{}, 2 * sec + 1, tile_col(sec), sector_src(more ? sec + 1 : 0), tile_col(sec + 1), more);
+        const unsigned *next = sector_src(more ? sec + 1 : 0);
+        task(std::integral_constant<int, 0>{}, 2 * sec, tile_col(sec), next, tile_col(sec + 1), more);
+        task(std::integral_constant<int, 1>{}, 2 * sec + 1, tile_col(sec), next, tile_col(sec + 1), more);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
