@@ -239,6 +239,14 @@ int wrp_debug_fused_stamps(wrp_handle h, const void *d_iq, int n_sectors, float 
  * Must equal those rows of wrp_dump_stage(WRP_STAGE_MID) bit for bit. */
 int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *host_mid, size_t host_bytes);
 
+/* Parity of the WHOLE intermediate: one fused launch (its diagnostics instantiation) whose tile workgroups also write
+ * everything they put through the hand-over slots -- both halves of every task -- to d_tee, device memory,
+ * [n_sectors][channels][m/2 gates][n] complex.  raw != 0: d_in is the wire format (12 bytes per sample) and the launch the
+ * wire-format one (m = 1024, n = 512 only).  Every [m/2][n] block must equal wrp_dump_stage(WRP_STAGE_MID) of that sector
+ * and channel bit for bit: the stage dumps come from the two-kernel path, this ties the launch the bench times to them
+ * (rpv2.cu:409-502: the reference's intermediate after its range FFT).  Synchronous. */
+int wrp_debug_fused_tee(wrp_handle h, const void *d_in, int raw, int n_sectors, float *d_out, void *d_tee, size_t tee_bytes);
+
 /* Introspection for harnesses. */
 int wrp_get_config(wrp_handle h, wrp_config *cfg);
 size_t wrp_sector_bytes(wrp_handle h);   /* channels*m*n*8 */

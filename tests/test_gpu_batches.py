@@ -287,3 +287,45 @@ def test_batch_entries_frame_their_products_for_the_wire(wrp, oracle, sectors, s
             assert e.fused_fallbacks == (1 if flags == wrp.FLAG_DEBUG_FUSED_UNDERSIZED and fused_shape else 0)
     with wrp.Engine(device=0, m=m, n=n, n_slots=1) as e:
         assert e.lib.wrp_process_batch_framed_device(e.handle, d_in.data_ptr(), count, d_out.data_ptr(), None, None, None) == -1
+
+
+@pytest.mark.parametrize("form", ["A", "A-wire", "B"])
+def test_the_whole_fused_intermediate_equals_the_two_kernel_range_pass(wrp, sectors, sectors_b, form):
+    """What the fused launches hand from their tile to their row workgroups never reaches global memory (it lives in the
+    XCDs' L2), and the stage dumps come from the two-kernel path.  `wrp_debug_fused_tee` runs the launch's own
+    instantiation that also copies EVERYTHING it puts through the slots -- both halves of every task, both channels, every
+    sector -- to a device buffer: each [m/2][n] block must equal the two-kernel path's WRP_STAGE_MID (= rows 0 .. m/2 - 1 of
+    02fft1, rpv2.cu:409-502) bit for bit, for the planar launch, the wire-format launch (its in-register decode included)
+    and the 2048 x 128 launch; the finals of the same launch equal the ordinary launch's."""
+    import ctypes as C
+    import torch
+    pool = sectors_b if form == "B" else sectors
+    m, n = pool[0].shape[1:]
+    count = 17                                   # three sectors on team 0: its second and third reuse the slot
+    batch = np.stack([_variant(pool, k) for k in range(count)])
+    raw = form == "A-wire"
+    if raw:
+        d_in = torch.from_numpy(np.stack([_wire(s) for s in batch])).cuda()
+    else:
+        d_in = torch.from_numpy(batch.view(np.float32)).cuda()
+    d_out = torch.zeros(count, m // 2, 2, device="cuda")
+    d_ref = torch.zeros_like(d_out)
+    d_tee = torch.full((count, 2, m // 2, n, 2), float("nan"), device="cuda")
+    with wrp.Engine(device=0, n_slots=1, m=m, n=n, max_batch=count) as e:
+        rc = e.lib.wrp_debug_fused_tee(e.handle, C.c_void_p(d_in.data_ptr()), int(raw), count, C.c_void_p(d_out.data_ptr()),
+                                       C.c_void_p(d_tee.data_ptr()), d_tee.numel() * 4)
+        assert rc == 0, e.lib.wrp_last_hip_error(e.handle)
+        torch.cuda.synchronize()
+        (e.process_batch_raw_device if raw else e.process_batch_device)(d_in.data_ptr(), count, d_ref.data_ptr())
+        e.check()
+        assert e.fused_fallbacks == 0
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), d_ref.cpu().numpy().view(np.uint32))
+        tee = d_tee.cpu().numpy().view(np.complex64)[..., 0]
+        assert not np.isnan(tee.view(np.float32)).any()
+        for k in (0, 5, 8, 16):
+            e.slot_array(0)[:] = batch[k]
+            e.submit(0, 0, 0)
+            e.wait(0)
+            for ch in (0, 1):
+                mid = e.dump_stage(0, "mid", ch)
+                assert np.array_equal(tee[k, ch].view(np.uint32), mid.view(np.uint32)), (form, k, ch)

@@ -135,6 +135,7 @@ def load_library():
     if hasattr(lib, "wrp_fused_launches"):
         lib.wrp_fused_launches.argtypes = [vp]
     lib.wrp_debug_fused_mid.argtypes = [vp, vp, i, vp, vp, C.c_size_t]
+    lib.wrp_debug_fused_tee.argtypes = [vp, vp, i, i, vp, vp, C.c_size_t]
     lib.wrp_dump_stage.argtypes = [vp, i, i, i, vp]
     lib.wrp_time_batch_device.argtypes = [vp, vp, i, vp, i, fp, fp, fp]
     lib.wrp_get_config.argtypes = [vp, C.POINTER(WrpConfig)]

@@ -285,8 +285,9 @@ Frames frames_at(Frames fr, const wrp_config &c, int sector)
 }
 
 // one persistent launch for the whole batch: XCD teams keep the intermediate in their L2 (wrp_fused.h)
+// d_stamps / d_tee: the diagnostics instantiations (phase stamps; a copy of the whole intermediate in global memory)
 int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_sectors, float *d_out, hipStream_t st, int slot,
-                 unsigned long long *d_stamps = nullptr, bool raw = false, Frames fr = Frames{})
+                 unsigned long long *d_stamps = nullptr, bool raw = false, Frames fr = Frames{}, float2 *d_tee = nullptr)
 {
     const wrp_config &c = h->cfg;
     // a successful launch leaves the control block zeroed (fused_leave): no memset node in front of the next one
@@ -297,38 +298,34 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
     const wrp::RangeConsts rc{h->d_wr, h->d_wd, h->d_tw_m};
     // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
+    const int form = d_tee ? 2 : d_stamps ? 1 : 0;      // which instantiation
     if (h->tuned_b) {
-#define WRP_FUSED_B(TAPS, STAMPS)                                                                                     \
-    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
+#define WRP_FUSED_B(TAPS, STAMPS, TEE)                                                                                \
+    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS, STAMPS, TEE>), dim3(grid), dim3(wrp::FUSED_THREADS),          \
                        wrp::FusedTileB::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
-                       fr.frames, fr.hdrs)
-        if (d_stamps) { if (h->taps_pad == 7) WRP_FUSED_B(7, true); else WRP_FUSED_B(9, true); }
-        else { if (h->taps_pad == 7) WRP_FUSED_B(7, false); else WRP_FUSED_B(9, false); }
+                       fr.frames, fr.hdrs, d_tee)
+        if (form == 2) { if (h->taps_pad == 7) WRP_FUSED_B(7, false, true); else WRP_FUSED_B(9, false, true); }
+        else if (form == 1) { if (h->taps_pad == 7) WRP_FUSED_B(7, true, false); else WRP_FUSED_B(9, true, false); }
+        else { if (h->taps_pad == 7) WRP_FUSED_B(7, false, false); else WRP_FUSED_B(9, false, false); }
 #undef WRP_FUSED_B
         HIP_TRY(h, hipGetLastError());
         return WRP_OK;
     }
-    if (raw) {   // the wire format straight into the tile workgroups (m = 1024, n = 512 only: the caller has checked)
-#define WRP_FUSED_RAW(TAPS)                                                                                           \
-    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, false, true>), dim3(grid), dim3(wrp::FUSED_THREADS),          \
-                       wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
-                       c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, nullptr,       \
-                       fr.frames, fr.hdrs)
-        if (h->taps_pad == 7) WRP_FUSED_RAW(7); else WRP_FUSED_RAW(9);
-#undef WRP_FUSED_RAW
-        HIP_TRY(h, hipGetLastError());
-        return WRP_OK;
-    }
-#define WRP_FUSED(TAPS, STAMPS)                                                                                       \
-    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS>), dim3(grid), dim3(wrp::FUSED_THREADS),               \
+#define WRP_FUSED(TAPS, STAMPS, RAW, TEE)                                                                             \
+    hipLaunchKernelGGL((wrp::fused_chain_1024x512<TAPS, STAMPS, RAW, TEE>), dim3(grid), dim3(wrp::FUSED_THREADS),     \
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
-                       fr.frames, fr.hdrs)
-    if (d_stamps) {
-        if (h->taps_pad == 7) WRP_FUSED(7, true); else WRP_FUSED(9, true);
+                       fr.frames, fr.hdrs, d_tee)
+    if (raw) {   // the wire format straight into the tile workgroups (m = 1024, n = 512 only: the caller has checked)
+        if (form == 2) { if (h->taps_pad == 7) WRP_FUSED(7, false, true, true); else WRP_FUSED(9, false, true, true); }
+        else { if (h->taps_pad == 7) WRP_FUSED(7, false, true, false); else WRP_FUSED(9, false, true, false); }
+    } else if (form == 2) {
+        if (h->taps_pad == 7) WRP_FUSED(7, false, false, true); else WRP_FUSED(9, false, false, true);
+    } else if (form == 1) {
+        if (h->taps_pad == 7) WRP_FUSED(7, true, false, false); else WRP_FUSED(9, true, false, false);
     } else {
-        if (h->taps_pad == 7) WRP_FUSED(7, false); else WRP_FUSED(9, false);
+        if (h->taps_pad == 7) WRP_FUSED(7, false, false, false); else WRP_FUSED(9, false, false, false);
     }
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
@@ -601,11 +598,12 @@ int create_impl(wrp_engine *h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
     // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
     h->fused = (h->tuned || h->tuned_b) && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
-#define WRP_FUSED_B_ATTR(TAPS, STAMPS)                                                                    \
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<TAPS, STAMPS>), \
+#define WRP_FUSED_B_ATTR(TAPS, STAMPS, TEE)                                                                    \
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<TAPS, STAMPS, TEE>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES))
-    WRP_FUSED_B_ATTR(7, false); WRP_FUSED_B_ATTR(9, false);
-    WRP_FUSED_B_ATTR(7, true);  WRP_FUSED_B_ATTR(9, true);
+    WRP_FUSED_B_ATTR(7, false, false); WRP_FUSED_B_ATTR(9, false, false);
+    WRP_FUSED_B_ATTR(7, true, false);  WRP_FUSED_B_ATTR(9, true, false);      // diagnostics: phase stamps
+    WRP_FUSED_B_ATTR(7, false, true);  WRP_FUSED_B_ATTR(9, false, true);      // diagnostics: the intermediate copied out
 #undef WRP_FUSED_B_ATTR
     h->fused_armed = h->fused;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
@@ -623,16 +621,15 @@ int create_impl(wrp_engine *h)
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
         h->n_cus = prop.multiProcessorCount;
     }
-#define WRP_FUSED_ATTR(TAPS, STAMPS)                                                                      \
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<TAPS, STAMPS>), \
+#define WRP_FUSED_ATTR(TAPS, STAMPS, RAW, TEE)                                                                      \
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<TAPS, STAMPS, RAW, TEE>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES))
-    WRP_FUSED_ATTR(7, false); WRP_FUSED_ATTR(9, false);
-    WRP_FUSED_ATTR(7, true);  WRP_FUSED_ATTR(9, true);
+    WRP_FUSED_ATTR(7, false, false, false); WRP_FUSED_ATTR(9, false, false, false);     // the launch
+    WRP_FUSED_ATTR(7, false, true, false);  WRP_FUSED_ATTR(9, false, true, false);      // wire-format input
+    WRP_FUSED_ATTR(7, true, false, false);  WRP_FUSED_ATTR(9, true, false, false);      // diagnostics: phase stamps
+    WRP_FUSED_ATTR(7, false, false, true);  WRP_FUSED_ATTR(9, false, false, true);      // diagnostics: the intermediate copied out
+    WRP_FUSED_ATTR(7, false, true, true);   WRP_FUSED_ATTR(9, false, true, true);
 #undef WRP_FUSED_ATTR
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<7, false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<9, false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES));
     HIP_TRY(h, hipEventCreateWithFlags(&h->lane.done, hipEventDisableTiming));
     HIP_TRY(h, hipMalloc(&h->lane.d_ctl, sizeof(wrp::FusedCtl)));
     HIP_TRY(h, hipMalloc(&h->lane.d_pool, sizeof(float2) * wrp::FUSED_TEAM_ELEMS * wrp::FUSED_MAX_TEAMS));
@@ -1070,18 +1067,20 @@ int wrp_time_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *
 }
 
 // one fused launch on the engine's stream, waited for; its status word is looked at here (no repeat)
-static int run_fused_sync_nocheck(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps);
+static int run_fused_sync_nocheck(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps,
+                                  bool raw = false, float2 *d_tee = nullptr);
 static int run_fused_sync(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps)
 {
     const int rc = wrp_check(h);
     return rc != WRP_OK ? rc : run_fused_sync_nocheck(h, d_iq, n_sectors, d_out, d_stamps);
 }
-static int run_fused_sync_nocheck(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps)
+static int run_fused_sync_nocheck(wrp_engine *h, const float2 *d_iq, int n_sectors, float *d_out, unsigned long long *d_stamps,
+                                  bool raw, float2 *d_tee)
 {
     int rc = WRP_OK;
     const int slot = h->ring_next;
     h->ring_next = (h->ring_next + 1) % WRP_RING;
-    rc = launch_fused(h, h->lane, d_iq, n_sectors, d_out, h->stream, slot, d_stamps);
+    rc = launch_fused(h, h->lane, d_iq, n_sectors, d_out, h->stream, slot, d_stamps, raw, Frames{}, d_tee);
     if (rc != WRP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     unsigned st = 0;
@@ -1131,6 +1130,18 @@ int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_
     if (rc != WRP_OK) return rc;
     HIP_TRY(h, hipMemcpy(host_mid, h->lane.d_pool, bytes, hipMemcpyDeviceToHost));
     return WRP_OK;
+}
+
+int wrp_debug_fused_tee(wrp_handle h, const void *d_in, int raw, int n_sectors, float *d_out, void *d_tee, size_t tee_bytes)
+{
+    if (!h || !d_in || !d_out || !d_tee || n_sectors < WRP_FUSED_MIN_SECTORS) return WRP_ERR_INVALID;
+    if (!h->tuned && !h->tuned_b) return WRP_ERR_UNSUPPORTED;
+    if (raw && !h->tuned) return WRP_ERR_UNSUPPORTED;     // the wire format goes INTO the launch for m = 1024, n = 512 only
+    const wrp_config &c = h->cfg;
+    if (tee_bytes < sizeof(float2) * (size_t)n_sectors * c.channels * (c.m / 2) * c.n) return WRP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int rc = wrp_check(h);
+    return rc != WRP_OK ? rc : run_fused_sync_nocheck(h, (const float2 *)d_in, n_sectors, d_out, nullptr, raw != 0, (float2 *)d_tee);
 }
 
 int wrp_get_config(wrp_handle h, wrp_config *cfg)

@@ -407,7 +407,9 @@ __device__ __forceinline__ void fused_stage3(unsigned char *smem, cf (&o)[2][4])
     fused_stage3_item<0>(smem, o);
     fused_stage3_item<1>(smem, o);
 }
-__device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4])
+// tee (diagnostics instantiation only, nullptr otherwise): the task's [512 gates][512] block of a copy of the whole
+// intermediate in global memory -- what tests compare with the two-kernel path's WRP_STAGE_MID, both halves
+__device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int col_base, int group, const cf (&o)[2][4], float2 *tee = nullptr)
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -424,6 +426,12 @@ __device__ __forceinline__ void fused_store(float2 *mid /* wave-uniform */, int 
             t.x = o[it][k3].x; t.y = o[it][k3].y;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (32 * it + 64 * k3) * DP_N * 8, 0, 0);
         }
+    if (tee) {
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+#pragma unroll
+            for (int k3 = 0; k3 < 4; k3++) tee[(size_t)(w + 8 * group + 16 * ((l >> 4) + 4 * it) + 128 * k3) * DP_N + col_base + col] = o[it][k3];
+    }
 }
 
 // Who am I: XCD, kind (the older / the younger of the two workgroups on this CU), rank inside the team.  Everything here
@@ -637,7 +645,8 @@ __device__ __forceinline__ void fused_raw_group1_to_lds(unsigned char *smem, con
 // copies) the launch is 1.3 % slower.  Eight pieces on the points 0 1 2 3 | 5 | 6 7 9 of a task's eleven; seven other
 // placements +0.0 ... +5.5 % (ab_wire_request_schedules.log).
 __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const unsigned *raw, float2 *mid, FusedCtl *ctl,
-                                                      const RangeConsts &rc, int xcc, int rank, int teams, int trank, int tasks)
+                                                      const RangeConsts &rc, int xcc, int rank, int teams, int trank, int tasks,
+                                                      float2 *tee /* diagnostics: see fused_store */)
 {
     typedef FusedTile T;
     const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
@@ -674,6 +683,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
     // one channel-task; it requests eight of the next sector's sixteen pieces (valid = false behind the last sector)
     auto task = [&](auto chc, int q, int col, const unsigned *next, int next_col, bool more) {
         constexpr int CH = decltype(chc)::value;
+        float2 *tee_task = tee ? tee + ((size_t)(trank + (q >> 1) * teams) * 2 + CH) * (RP_M / 2) * DP_N : nullptr;
         cf ga[8], gc[8];
         if (CH == 0) {
             float hh[32];
@@ -702,7 +712,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         fused_stage3_item<1, false>(smem, o);
         spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
         __syncthreads();                    // A2
-        fused_store(mid, col, 0, o);
+        fused_store(mid, col, 0, o, tee_task);
         __builtin_amdgcn_sched_barrier(0);
         WRP_LR(1);
         fused_raw_group1_to_lds(smem, ga, gc);
@@ -721,7 +731,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
 #undef WRP_LR
         spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
         __syncthreads();                    // A4
-        fused_store(mid, col, 1, o);
+        fused_store(mid, col, 1, o, tee_task);
     };
 #pragma unroll 1
     for (int sec = 0; sec < sectors; sec++) {
@@ -747,7 +757,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
 #else
 #define WRP_NO_DS_MERGE
 #endif
-template <int TAPS, bool STAMPS, bool RAW = false>
+template <int TAPS, bool STAMPS, bool RAW = false, bool TEE = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) WRP_NO_DS_MERGE void fused_chain_1024x512(
     const float2 *__restrict__ iq,   // [S][C][1024][512]; RAW: the wire format, [S][1024 x 512][12 bytes]
     float *__restrict__ out,         // [S][512][2]
@@ -755,7 +765,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
     float k_rr, float k_cal, unsigned *host_status /* pinned host word of this launch */,
     unsigned long long *stamps /* diagnostics: [grid][FUSED_STAMP_TASKS][8] or nullptr */,
-    unsigned *frames /* optional (N2): [S][2][1 + 512] words, the products framed for the wire */, const unsigned *frame_hdrs /* [S] header words */)
+    unsigned *frames /* optional (N2): [S][2][1 + 512] words, the products framed for the wire */, const unsigned *frame_hdrs /* [S] header words */,
+    float2 *tee /* diagnostics (TEE instantiations): [S][C][512][512], a copy of everything that goes through the slots */)
 {
     typedef FusedTile T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     };
 
     if (RAW && kind == 0) {
-        fused_raw_tile_member(smem, reinterpret_cast<const unsigned *>(iq), mid, ctl, rc, xcc, rank, teams, trank, tasks);
+        fused_raw_tile_member(smem, reinterpret_cast<const unsigned *>(iq), mid, ctl, rc, xcc, rank, teams, trank, tasks, TEE ? tee : nullptr);
         fused_leave(ctl, host_status, xcc, s_ctl);
     } else if (kind == 0) {
         // =============================== tile member ===============================
@@ -874,7 +885,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             // stores go out.
             spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
-            fused_store(mid, tile_col(q), 0, o);
+            float2 *tee_task = TEE && tee ? tee + ((size_t)(trank + (q >> 1) * teams) * channels + (q & 1)) * (RP_M / 2) * n : nullptr;
+            fused_store(mid, tile_col(q), 0, o, tee_task);
             // BEHIND the stores, so that a counted wait can tell them apart: the scheduling barrier keeps the four loads
             // below the eight stores whatever alias analysis says about `iq` (restrict) and the descriptor
             __builtin_amdgcn_sched_barrier(0);
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             stamp(q, 7);
             __syncthreads();                    // A4: image free for the next stage 1; the slot is free for half 1 (the rows have half 0 of THIS task)
-            fused_store(mid, tile_col(q), 1, o);
+            fused_store(mid, tile_col(q), 1, o, tee_task);
             stamp(q, 4);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -198,7 +198,8 @@ __device__ __forceinline__ int fused_b_gate(int g, int Q, int pb)
 {
     return 8 * g + (Q & 7) + 16 * (2 * ((Q >> 3) & 3) + pb + 8 * ((Q >> 5) & 1)) + 256 * (Q >> 6);
 }
-__device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, int ch, int col_base, const cf (&o)[2][4])
+// tee (diagnostics instantiation only): the sector-channel's [1024 gates][128] block of a copy of the intermediate, g: the half
+__device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, int ch, int col_base, const cf (&o)[2][4], float2 *tee = nullptr, int g = 0)
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -214,16 +215,24 @@ __device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, in
             t.x = o[it][k3].x; t.y = o[it][k3].y;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, t), rd, voff + (k3 * 2 + it) * 4 * 8 * 16 * 128, 0, 0);
         }
+    if (tee) {
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+#pragma unroll
+            for (int k3 = 0; k3 < 4; k3++)
+                tee[(size_t)fused_b_gate(g, ((k3 * 2 + it) * 4 + (k2l >> 1)) * 8 + w, k2l & 1) * RB_N + col_base + c8] = o[it][k3];
+    }
 }
 
-template <int TAPS, bool STAMPS = false>
+template <int TAPS, bool STAMPS = false, bool TEE = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_2048x128(
     const float2 *__restrict__ iq,   // [S][C][2048][128]
     float *__restrict__ out,         // [S][1024][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS]: per team ONE slot [2 channels][512][128] through which both halves go
     FusedCtl *ctl, RangeConsts rc /* wr_c symmetric */, const float2 *__restrict__ tw_n /* exp(+2 pi i k / 128) */, int n_sectors,
     int channels, MaTaps taps, float k_rr, float k_cal, unsigned *host_status, unsigned long long *stamps /* STAMPS instantiation: [grid][FUSED_STAMP_TASKS][9] */,
-    unsigned *frames /* optional (N2): [S][2][1 + 1024] words */, const unsigned *frame_hdrs /* [S] header words */)
+    unsigned *frames /* optional (N2): [S][2][1 + 1024] words */, const unsigned *frame_hdrs /* [S] header words */,
+    float2 *tee /* diagnostics (TEE instantiation): [S][C][1024][128], a copy of everything that goes through the slots */)
 {
     typedef FusedTileB T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -321,7 +330,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             WRP_LB(1); WRP_LB(9);
             spin_flags_sticky(my_loaded1, (unsigned)q, failed, w != 0);     // the slot still holds half 1 of task q - 1
             __syncthreads();                    // A2: group 0 has left the image; the slot is free for half 0
-            fused_b_store(mid, ch, col_base, o);
+            float2 *tee_task = TEE && tee ? tee + ((size_t)(trank + q * teams) * channels + ch) * (RB_M / 2) * RB_N : nullptr;
+            fused_b_store(mid, ch, col_base, o, tee_task, 0);
             __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
             WRP_LB(5); WRP_LB(13); WRP_LB(2); WRP_LB(10);
             fused_b_group1_to_lds(smem, ga, gc);
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             spin_flags_sticky(my_loaded0, (unsigned)(q + 1), failed, w != 0);
             stamp(q, 4);
             __syncthreads();                    // A4: image free for the next stage 1; the rows have half 0 of THIS task
-            fused_b_store(mid, ch, col_base, o);
+            fused_b_store(mid, ch, col_base, o, tee_task, 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
