@@ -155,6 +155,9 @@ void make_taps(int count, wrp::MaTaps &t)
         sum += g[i];
     }
     for (int i = 0; i < 9; i++) t.g[i] = i < count ? (float)(g[i] / sum) : 0.f;
+    double s = 0;       // what the rows multiply their sum of |.|^2 by: the sum of the taps AS ROUNDED (doppler_row: a7 + a8)
+    for (int i = 0; i < count; i++) s += (double)t.g[i];
+    t.sum = (float)s;
 }
 
 template <int TCOLS, bool DUMP>

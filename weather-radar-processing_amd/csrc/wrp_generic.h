@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64) void generic_doppler_pass(
             wave_lds_fence();
         }
         // position bitrev(k) holds Z[k]; post-shift bin j is Z[(j + n/2) mod n]
+        float part = 0.f;
         for (int j = l; j < n; j += 64) {
             const int k = (j + n / 2) & (n - 1);
             cf z = buf[bitrev(k, log2n)];
@@ -97,19 +98,19 @@ __global__ __launch_bounds__(64) void generic_doppler_pass(
             if (j >= n - 2) z = make_float2(0.f, 0.f);
             if (do_dump && dump.fft2) dump.fft2[(size_t)gate * n + j] = z;
             const float a = fmaf(z.y, z.y, z.x * z.x);
-            abuf[j] = a;
+            part += a;
+            if (DUMP) abuf[j] = a;
             if (do_dump && dump.abs2) dump.abs2[(size_t)gate * n + j] = a;
         }
         wave_lds_fence();
-        float part = 0.f;
-        for (int j = l; j < n; j += 64) {
-            float p = 0.f;
+        if (DUMP && do_dump && dump.pow)    // a7 as a stage only: its row sum is (sum of the taps) x (sum of |.|^2), see doppler_row
+            for (int j = l; j < n; j += 64) {
+                float p = 0.f;
 #pragma unroll
-            for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], abuf[(j - t) & (n - 1)], p);
-            if (do_dump && dump.pow) dump.pow[(size_t)gate * n + j] = p;
-            part += p;
-        }
-        S[ch] = wave_sum(part);
+                for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], abuf[(j - t) & (n - 1)], p);
+                dump.pow[(size_t)gate * n + j] = p;
+            }
+        S[ch] = wave_sum(part) * taps.sum;
         if (do_dump && dump.rowsum && l == 0) dump.rowsum[gate] = S[ch];
         wave_lds_fence();
     }

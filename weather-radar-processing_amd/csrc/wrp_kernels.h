@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned *sector_frames(const DumpPtrs &d, int sec, i
 // status word in device memory (0 = it succeeded, there is nothing to repeat); nullptr = not gated
 __device__ __forceinline__ bool gate_closed(const unsigned *gate /* wave-uniform */) { return gate && *gate == 0; }
 
-struct MaTaps { float g[9]; };
+struct MaTaps { float g[9]; float sum; };   // sum = g[0] + ... + g[count-1], formed in double from the rounded taps
 
 struct RangeConsts {
     const float *wr_c;   // [1024]  range window * c
@@ -535,43 +535,52 @@ __device__ __forceinline__ float doppler_row(cf (&v)[8], float2 *buf, const floa
             dump.noshift[(size_t)gate * DP_N + klo + 64 * k3] = make_float2(v[k3].x, -v[k3].y);
     }
     // shift (swap halves: j = k + n/2 mod n), clip post-shift bins n-1, n-2, |.|^2
+    // a7 + a8: the chain needs the moving average (read.cc:290-301: a CIRCULAR convolution, FFT x H x inverse FFT) only
+    // through its row sum (read.cc:303-311), and the sum of a circular convolution is its DC bin:
+    //   sum_j sum_t g[t] A[(j - t) mod n] = (sum_t g[t]) (sum_j A[j]).
+    // So the launch sums |.|^2 where the Doppler transform leaves it, in registers, and multiplies by the taps' sum; the
+    // convolution itself (08pow) is formed by the DUMP instantiations only, for the stage dump -- 56 of a row's 456
+    // vector instructions and 12 of its 47 LDS instructions less.  Every launch form shares this function.
     const int fb = klo + 4 * (klo >> 3);
+    float part = 0.f;
 #pragma unroll
     for (int k3 = 0; k3 < 8; k3++) {
         const int j = ((k3 + 4) & 7) * 64 + klo;
         cf z = v[k3];
         if (j >= DP_N - 2) z = make_float2(0.f, 0.f);
         if (DUMP && do_dump && dump.fft2) dump.fft2[(size_t)gate * DP_N + j] = z;
-        fbuf[fb + 96 * ((k3 + 4) & 7)] = fmaf(z.y, z.y, z.x * z.x);   // = dp_fidx(j): j + 4 (j >> 3) with klo < 64
+        const float p2 = fmaf(z.y, z.y, z.x * z.x);
+        part += p2;
+        if (DUMP) fbuf[fb + 96 * ((k3 + 4) & 7)] = p2;   // = dp_fidx(j): j + 4 (j >> 3) with klo < 64
     }
-    wave_lds_fence();
-    // a7: P[j] = sum_t g[t] A[(j - t) mod n]; lane owns j = 8 l .. 8 l + 7 plus an 8-bin halo
-    float a[16];
-    {
-        const float4 *f4 = reinterpret_cast<const float4 *>(fbuf);
-        const int prev = 3 * ((l + 63) & 63);   // float4 index of bin 8 l - 8 (mod 512) under dp_fidx
-        const float4 h0 = f4[prev], h1 = f4[prev + 1], c0 = f4[3 * l], c1 = f4[3 * l + 1];
-        a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
-        a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
-        a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
-        a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
-    }
-    if (DUMP && do_dump && dump.abs2) {
+    const float S = wave_sum(part) * taps.sum;     // a8: row sum
+    if (DUMP) {
+        wave_lds_fence();
+        // a7 as a stage: P[j] = sum_t g[t] A[(j - t) mod n]; lane owns j = 8 l .. 8 l + 7 plus an 8-bin halo
+        float a[16];
+        {
+            const float4 *f4 = reinterpret_cast<const float4 *>(fbuf);
+            const int prev = 3 * ((l + 63) & 63);   // float4 index of bin 8 l - 8 (mod 512) under dp_fidx
+            const float4 h0 = f4[prev], h1 = f4[prev + 1], c0 = f4[3 * l], c1 = f4[3 * l + 1];
+            a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
+            a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
+            a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
+            a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
+        }
+        if (do_dump && dump.abs2) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * DP_N + 8 * l + u] = a[8 + u];
-    }
-    float part = 0.f;
+            for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * DP_N + 8 * l + u] = a[8 + u];
+        }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        float p = 0.f;
+        for (int u = 0; u < 8; u++) {
+            float p = 0.f;
 #pragma unroll
-        for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
-        if (DUMP && do_dump && dump.pow) dump.pow[(size_t)gate * DP_N + 8 * l + u] = p;
-        part += p;
+            for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
+            if (do_dump && dump.pow) dump.pow[(size_t)gate * DP_N + 8 * l + u] = p;
+        }
+        if (do_dump && dump.rowsum && l == 0) dump.rowsum[gate] = S;
+        wave_lds_fence();   // conv reads done before the buffer's next use
     }
-    const float S = wave_sum(part);                // a8: row sum
-    if (DUMP && do_dump && dump.rowsum && l == 0) dump.rowsum[gate] = S;
-    wave_lds_fence();   // conv reads done before the buffer's next use
     return S;
 }
 

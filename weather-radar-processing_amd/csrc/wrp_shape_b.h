@@ -283,6 +283,7 @@ __device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const 
     }
     wave_lds_fence();   // everyone has read before the buffer is reused for |.|^2
     // shift (swap halves), clip post-shift bins n-1, n-2, |.|^2 in natural order
+    float part = 0.f;
     {
         const int k2 = i & 3;
 #pragma unroll
@@ -296,38 +297,42 @@ __device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const 
                 if (DUMP && do_dump && dump.noshift) dump.noshift[(size_t)gate * RB_N + k] = make_float2(z.x, -z.y);   // before the final conj
                 if (j >= RB_N - 2) z = make_float2(0.f, 0.f);
                 if (DUMP && do_dump && dump.fft2) dump.fft2[(size_t)gate * RB_N + j] = z;
-                fbuf[db_fidx(j)] = fmaf(z.y, z.y, z.x * z.x);
+                const float p2 = fmaf(z.y, z.y, z.x * z.x);
+                part += p2;
+                if (DUMP) fbuf[db_fidx(j)] = p2;
             }
         }
     }
-    wave_lds_fence();
-    // a7: lane owns bins 8 i .. 8 i + 7 plus an 8-bin halo (circular over the 16 lanes of the row)
-    float a[16];
-    {
-        const float4 *f4 = reinterpret_cast<const float4 *>(fbuf);
-        const int prev = 3 * ((i + 15) & 15);
-        const float4 h0 = f4[prev], h1 = f4[prev + 1], c0 = f4[3 * i], c1 = f4[3 * i + 1];
-        a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
-        a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
-        a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
-        a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
-    }
-    if (DUMP && do_dump && dump.abs2) {
+    // a7 + a8: the row sum of the circular moving average is (sum of the taps) x (sum of |.|^2) -- see doppler_row
+    // (wrp_kernels.h); the convolution itself is formed by the DUMP instantiation only, for the 08pow stage
+    const float S = row16_sum(part) * taps.sum;
+    if (DUMP) {
+        wave_lds_fence();
+        // a7 as a stage: lane owns bins 8 i .. 8 i + 7 plus an 8-bin halo (circular over the 16 lanes of the row)
+        float a[16];
+        {
+            const float4 *f4 = reinterpret_cast<const float4 *>(fbuf);
+            const int prev = 3 * ((i + 15) & 15);
+            const float4 h0 = f4[prev], h1 = f4[prev + 1], c0 = f4[3 * i], c1 = f4[3 * i + 1];
+            a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
+            a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
+            a[8] = c0.x; a[9] = c0.y; a[10] = c0.z; a[11] = c0.w;
+            a[12] = c1.x; a[13] = c1.y; a[14] = c1.z; a[15] = c1.w;
+        }
+        if (do_dump && dump.abs2) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * RB_N + 8 * i + u] = a[8 + u];
-    }
-    float part = 0.f;
+            for (int u = 0; u < 8; u++) dump.abs2[(size_t)gate * RB_N + 8 * i + u] = a[8 + u];
+        }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        float p = 0.f;
+        for (int u = 0; u < 8; u++) {
+            float p = 0.f;
 #pragma unroll
-        for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
-        if (DUMP && do_dump && dump.pow) dump.pow[(size_t)gate * RB_N + 8 * i + u] = p;
-        part += p;
+            for (int t = 0; t < TAPS; t++) p = fmaf(taps.g[t], a[8 + u - t], p);
+            if (do_dump && dump.pow) dump.pow[(size_t)gate * RB_N + 8 * i + u] = p;
+        }
+        if (do_dump && dump.rowsum && i == 0) dump.rowsum[gate] = S;
+        wave_lds_fence();
     }
-    const float S = row16_sum(part);
-    if (DUMP && do_dump && dump.rowsum && i == 0) dump.rowsum[gate] = S;
-    wave_lds_fence();
     return S;
 }
 
