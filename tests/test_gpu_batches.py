@@ -329,3 +329,37 @@ def test_the_whole_fused_intermediate_equals_the_two_kernel_range_pass(wrp, sect
             for ch in (0, 1):
                 mid = e.dump_stage(0, "mid", ch)
                 assert np.array_equal(tee[k, ch].view(np.uint32), mid.view(np.uint32)), (form, k, ch)
+
+
+@pytest.mark.parametrize("form", ["A", "A-wire", "B"])
+def test_fused_launches_at_ragged_batch_sizes_back_to_back(wrp, sectors, sectors_b, form):
+    """The persistent launches deal sectors to 8 teams (sector s to team s mod 8): batch sizes that are no multiple of 8,
+    one sector more or less than a multiple, a single task per team, more than 45 per team -- queued back to back on the
+    engine's stream without a host synchronisation in between (four launches in flight share the status ring) -- must
+    each give, sector for sector, the bits of the two-kernel path."""
+    import torch
+    pool = sectors_b if form == "B" else sectors
+    m, n = pool[0].shape[1:]
+    total = 360
+    raw = form == "A-wire"
+    if raw:
+        d_pool = torch.from_numpy(np.stack([_wire(s) for s in pool])).cuda().view(len(pool), m, n, 12)
+    else:
+        d_pool = torch.from_numpy(np.stack(pool).view(np.float32)).cuda().view(len(pool), 2, m, n, 2)
+    # sector k: pool sector k mod 3 with its pulses rotated by k (distinct sectors, still exact int16 values)
+    d_in = torch.stack([torch.roll(d_pool[k % len(pool)], shifts=k, dims=-2) for k in range(total)]).contiguous()
+    sizes = [8, 9, 15, 16, 17, 23, 64, 97, 257, 360, 8]
+    d_ref = torch.zeros(total, m // 2, 2, device="cuda")
+    with wrp.Engine(device=0, n_slots=1, m=m, n=n, max_batch=32, flags=wrp.FLAG_TWO_KERNELS) as e2:
+        (e2.process_batch_raw_device if raw else e2.process_batch_device)(d_in.data_ptr(), total, d_ref.data_ptr())
+        e2.check()
+    ref = d_ref.cpu().numpy().view(np.uint32)
+    outs = [torch.full((s, m // 2, 2), float("nan"), device="cuda") for s in sizes]
+    with wrp.Engine(device=0, n_slots=1, m=m, n=n, max_batch=32) as e:
+        for s, d_out in zip(sizes, outs):
+            (e.process_batch_raw_device if raw else e.process_batch_device)(d_in.data_ptr(), s, d_out.data_ptr())
+        e.check()
+        assert e.fused_fallbacks == 0
+        assert e.fused_launches >= len(sizes)
+    for s, d_out in zip(sizes, outs):
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), ref[:s]), (form, s)
