@@ -162,11 +162,11 @@ int wrp_process_device(wrp_handle h, const void *d_iq, float *d_out, void *strea
 int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream);
 /* The same for a batch in the WIRE format: d_raw = [n_sectors][m*n samples][12 bytes], hhI hhQ vvI vvQ vhI
  * vhQ as big-endian int16 (sector.cpp:52-62) -- what wrp_pinned_raw_slot takes, for a whole sweep that already lies in
- * device memory.  m = 1024, n = 512, >= WRP_FUSED_MIN_SECTORS sectors: the tile workgroups of the persistent launch read
- * the samples themselves (byte swap + conversion in registers, in place of the fp32 loads): 6 MiB of HBM reads per sector
- * instead of 8 and no decode pass.  m = 2048, n = 128: the batch is decoded on the GPU (up to max_batch sectors at a time)
- * in front of that shape's persistent launch.  Otherwise (small batches, other shapes, WRP_FLAG_TWO_KERNELS) it is
- * decoded in front of the two kernels.  Results are bit-identical to Sector::fromByteArray + the scatter of
+ * device memory.  m = 1024, n = 512 and m = 2048, n = 128, >= WRP_FUSED_MIN_SECTORS sectors: the tile workgroups of the
+ * persistent launch read the samples themselves (byte swap + conversion in registers, in place of the fp32 loads): 6 MiB
+ * (3 MiB) of HBM reads per sector instead of 8 (4) and no decode pass.  Otherwise (small batches, other shapes,
+ * WRP_FLAG_TWO_KERNELS, the repeat of a launch that gave up) the batch is decoded on the GPU, up to max_batch sectors at a
+ * time, in front of the two kernels.  Results are bit-identical to Sector::fromByteArray + the scatter of
  * rpv2.cu:372-383 + wrp_process_batch_device. */
 int wrp_process_batch_raw_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *stream);
 
@@ -242,7 +242,7 @@ int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_
 /* Parity of the WHOLE intermediate: one fused launch (its diagnostics instantiation) whose tile workgroups also write
  * everything they put through the hand-over slots -- both halves of every task -- to d_tee, device memory,
  * [n_sectors][channels][m/2 gates][n] complex.  raw != 0: d_in is the wire format (12 bytes per sample) and the launch the
- * wire-format one (m = 1024, n = 512 only).  Every [m/2][n] block must equal wrp_dump_stage(WRP_STAGE_MID) of that sector
+ * wire-format one.  Every [m/2][n] block must equal wrp_dump_stage(WRP_STAGE_MID) of that sector
  * and channel bit for bit: the stage dumps come from the two-kernel path, this ties the launch the bench times to them
  * (rpv2.cu:409-502: the reference's intermediate after its range FFT).  Synchronous. */
 int wrp_debug_fused_tee(wrp_handle h, const void *d_in, int raw, int n_sectors, float *d_out, void *d_tee, size_t tee_bytes);

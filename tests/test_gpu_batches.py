@@ -6,7 +6,7 @@
   * batches on a CALLER's stream are right by stream order alone, also when the fused launch gives up (the gated repeat
     queued behind it): the input may be overwritten as soon as the stream has passed the batch;
   * the framed products of the batch entries (SURVEY 8f N2: rpv2.cu:631-661, read_single.cc:510-520), byte-exact;
-  * 2048 x 128 wire-format batches take that shape's fused launch.
+  * 2048 x 128 wire-format batches go straight into that shape's fused launch (in-register decode).
 """
 import numpy as np
 import pytest
@@ -139,8 +139,9 @@ def test_wire_format_batches_with_a_workspace_smaller_than_the_batch(wrp, sector
 
 
 def test_shape_b_wire_format_batches_take_the_fused_launch(wrp, sectors_b):
-    """2048 x 128 wire-format batches: decoded on the GPU in front of that shape's persistent launch (not the two kernels);
-    max_batch = 8 makes a 19-sector batch go in three pieces (8 + 8 fused, 3 on the two kernels)."""
+    """2048 x 128 wire-format batches go straight into that shape's persistent launch (its tile workgroups read the 12-byte
+    samples: no decode pass, no workspace -- a 19-sector batch is ONE launch whatever max_batch is); a launch that gives up
+    is repeated from the raw bytes through decode_wire + the two kernels, max_batch sectors at a time."""
     import torch
     m, n = 2048, 128
     count = 19
@@ -149,18 +150,14 @@ def test_shape_b_wire_format_batches_take_the_fused_launch(wrp, sectors_b):
     d_out = torch.zeros(count, m // 2, 2, device="cuda")
     with wrp.Engine(device=0, m=m, n=n, n_slots=1, flags=wrp.FLAG_TWO_KERNELS) as e2:
         want = e2.process_host(planar)
-    with wrp.Engine(device=0, m=m, n=n, n_slots=1) as e:
-        e.process_batch_raw_device(d_raw.data_ptr(), count, d_out.data_ptr())
-        e.check()
-        assert e.fused_launches == 1 and e.fused_fallbacks == 0
-        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
-    with wrp.Engine(device=0, m=m, n=n, n_slots=1, max_batch=8) as e:
-        d_out.zero_()
-        e.process_batch_raw_device(d_raw.data_ptr(), count, d_out.data_ptr())
-        e.check()
-        assert e.fused_launches == 2 and e.fused_fallbacks == 0
-        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
-    with wrp.Engine(device=0, m=m, n=n, n_slots=1, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:
+    for max_batch in (32, 8):
+        with wrp.Engine(device=0, m=m, n=n, n_slots=1, max_batch=max_batch) as e:
+            d_out.zero_()
+            e.process_batch_raw_device(d_raw.data_ptr(), count, d_out.data_ptr())
+            e.check()
+            assert e.fused_launches == 1 and e.fused_fallbacks == 0
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    with wrp.Engine(device=0, m=m, n=n, n_slots=1, max_batch=8, flags=wrp.FLAG_DEBUG_FUSED_UNDERSIZED) as e:
         d_out.zero_()
         e.process_batch_raw_device(d_raw.data_ptr(), count, d_out.data_ptr())
         e.check()
@@ -289,7 +286,7 @@ def test_batch_entries_frame_their_products_for_the_wire(wrp, oracle, sectors, s
         assert e.lib.wrp_process_batch_framed_device(e.handle, d_in.data_ptr(), count, d_out.data_ptr(), None, None, None) == -1
 
 
-@pytest.mark.parametrize("form", ["A", "A-wire", "B"])
+@pytest.mark.parametrize("form", ["A", "A-wire", "B", "B-wire"])
 def test_the_whole_fused_intermediate_equals_the_two_kernel_range_pass(wrp, sectors, sectors_b, form):
     """What the fused launches hand from their tile to their row workgroups never reaches global memory (it lives in the
     XCDs' L2), and the stage dumps come from the two-kernel path.  `wrp_debug_fused_tee` runs the launch's own
@@ -299,11 +296,11 @@ def test_the_whole_fused_intermediate_equals_the_two_kernel_range_pass(wrp, sect
     and the 2048 x 128 launch; the finals of the same launch equal the ordinary launch's."""
     import ctypes as C
     import torch
-    pool = sectors_b if form == "B" else sectors
+    pool = sectors_b if form.startswith("B") else sectors
     m, n = pool[0].shape[1:]
     count = 17                                   # three sectors on team 0: its second and third reuse the slot
     batch = np.stack([_variant(pool, k) for k in range(count)])
-    raw = form == "A-wire"
+    raw = form.endswith("-wire")
     if raw:
         d_in = torch.from_numpy(np.stack([_wire(s) for s in batch])).cuda()
     else:
@@ -331,17 +328,17 @@ def test_the_whole_fused_intermediate_equals_the_two_kernel_range_pass(wrp, sect
                 assert np.array_equal(tee[k, ch].view(np.uint32), mid.view(np.uint32)), (form, k, ch)
 
 
-@pytest.mark.parametrize("form", ["A", "A-wire", "B"])
+@pytest.mark.parametrize("form", ["A", "A-wire", "B", "B-wire"])
 def test_fused_launches_at_ragged_batch_sizes_back_to_back(wrp, sectors, sectors_b, form):
     """The persistent launches deal sectors to 8 teams (sector s to team s mod 8): batch sizes that are no multiple of 8,
     one sector more or less than a multiple, a single task per team, more than 45 per team -- queued back to back on the
     engine's stream without a host synchronisation in between (four launches in flight share the status ring) -- must
     each give, sector for sector, the bits of the two-kernel path."""
     import torch
-    pool = sectors_b if form == "B" else sectors
+    pool = sectors_b if form.startswith("B") else sectors
     m, n = pool[0].shape[1:]
     total = 360
-    raw = form == "A-wire"
+    raw = form.endswith("-wire")
     if raw:
         d_pool = torch.from_numpy(np.stack([_wire(s) for s in pool])).cuda().view(len(pool), m, n, 12)
     else:

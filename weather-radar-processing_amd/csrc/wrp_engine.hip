@@ -303,14 +303,17 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
     const int form = d_tee ? 2 : d_stamps ? 1 : 0;      // which instantiation
     if (h->tuned_b) {
-#define WRP_FUSED_B(TAPS, STAMPS, TEE)                                                                                \
-    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS, STAMPS, TEE>), dim3(grid), dim3(wrp::FUSED_THREADS),          \
+#define WRP_FUSED_B(TAPS, STAMPS, TEE, RAW)                                                                           \
+    hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS, STAMPS, TEE, RAW>), dim3(grid), dim3(wrp::FUSED_THREADS),     \
                        wrp::FusedTileB::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
                        fr.frames, fr.hdrs, d_tee)
-        if (form == 2) { if (h->taps_pad == 7) WRP_FUSED_B(7, false, true); else WRP_FUSED_B(9, false, true); }
-        else if (form == 1) { if (h->taps_pad == 7) WRP_FUSED_B(7, true, false); else WRP_FUSED_B(9, true, false); }
-        else { if (h->taps_pad == 7) WRP_FUSED_B(7, false, false); else WRP_FUSED_B(9, false, false); }
+        if (raw) {   // the wire format straight into the tile workgroups
+            if (form == 2) { if (h->taps_pad == 7) WRP_FUSED_B(7, false, true, true); else WRP_FUSED_B(9, false, true, true); }
+            else { if (h->taps_pad == 7) WRP_FUSED_B(7, false, false, true); else WRP_FUSED_B(9, false, false, true); }
+        } else if (form == 2) { if (h->taps_pad == 7) WRP_FUSED_B(7, false, true, false); else WRP_FUSED_B(9, false, true, false); }
+        else if (form == 1) { if (h->taps_pad == 7) WRP_FUSED_B(7, true, false, false); else WRP_FUSED_B(9, true, false, false); }
+        else { if (h->taps_pad == 7) WRP_FUSED_B(7, false, false, false); else WRP_FUSED_B(9, false, false, false); }
 #undef WRP_FUSED_B
         HIP_TRY(h, hipGetLastError());
         return WRP_OK;
@@ -320,7 +323,7 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
                        fr.frames, fr.hdrs, d_tee)
-    if (raw) {   // the wire format straight into the tile workgroups (m = 1024, n = 512 only: the caller has checked)
+    if (raw) {   // the wire format straight into the tile workgroups
         if (form == 2) { if (h->taps_pad == 7) WRP_FUSED(7, false, true, true); else WRP_FUSED(9, false, true, true); }
         else { if (h->taps_pad == 7) WRP_FUSED(7, false, true, false); else WRP_FUSED(9, false, true, false); }
     } else if (form == 2) {
@@ -493,21 +496,10 @@ int submit_fused_piece(wrp_engine *h, const float2 *in, int n_sectors, float *d_
     if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // control block and slots are free again (free on one stream)
     const int slot = h->ring_next;
     h->ring_next = (h->ring_next + 1) % WRP_RING;
-    const bool decode_first = raw && h->tuned_b;   // 2048 x 128: the batch is decoded, then its fused launch reads the planar block
-    int rc = WRP_OK;
-    if (decode_first) {
-        rc = workspace_acquire(h, st);
-        if (rc != WRP_OK) return rc;
-        launch_decode(h, (const unsigned char *)in, n_sectors, st);
-    }
-    rc = launch_fused(h, lane, decode_first ? h->d_decode : in, n_sectors, d_out, st, slot, nullptr, raw && !decode_first, fr);
+    int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot, nullptr, raw, fr);
     if (rc != WRP_OK) return rc;
     h->fused_launches++;
     HIP_TRY(h, hipEventRecord(h->ev_ring[slot], st));
-    if (decode_first) {
-        rc = workspace_release(h, st);
-        if (rc != WRP_OK) return rc;
-    }
     if (stream) {
         const unsigned *gate = &lane.d_ctl->status;
         rc = raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, st, fr, gate)
@@ -520,21 +512,10 @@ int submit_fused_piece(wrp_engine *h, const float2 *in, int n_sectors, float *d_
     return WRP_OK;
 }
 
-// one batch through the fused launch; a wire-format batch of the 2048 x 128 shape goes piece by piece (decode workspace)
+// one batch through the fused launch (planar or wire format: both tuned shapes decode in their tile workgroups)
 int submit_fused(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream, bool raw = false, Frames fr = Frames{})
 {
-    if (!(raw && h->tuned_b)) return submit_fused_piece(h, in, n_sectors, d_out, stream, raw, fr);
-    const wrp_config &c = h->cfg;
-    int rc = ensure_decode(h, n_sectors);
-    const unsigned char *raw_bytes = (const unsigned char *)in;
-    for (int s0 = 0; rc == WRP_OK && s0 < n_sectors; s0 += h->decode_cap) {
-        const int cnt = std::min(h->decode_cap, n_sectors - s0);
-        const float2 *piece = (const float2 *)(raw_bytes + (size_t)s0 * c.m * c.n * 12);
-        float *out = d_out + (size_t)s0 * (c.m / 2) * 2;
-        if (cnt >= WRP_FUSED_MIN_SECTORS && h->fused_armed) rc = submit_fused_piece(h, piece, cnt, out, stream, true, frames_at(fr, c, s0));
-        else rc = launch_two_kernel_raw_batch(h, (const unsigned char *)piece, cnt, out, stream ? stream : h->stream, frames_at(fr, c, s0));
-    }
-    return rc;
+    return submit_fused_piece(h, in, n_sectors, d_out, stream, raw, fr);
 }
 
 // [sector BE16][elevation BE16] as one little-endian word of device / host memory
@@ -601,12 +582,14 @@ int create_impl(wrp_engine *h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
     // the fused launch is the default for the tuned shape; WRP_FLAG_TWO_KERNELS keeps the pair of kernels
     h->fused = (h->tuned || h->tuned_b) && (c.flags & WRP_FLAG_TWO_KERNELS) == 0;
-#define WRP_FUSED_B_ATTR(TAPS, STAMPS, TEE)                                                                    \
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<TAPS, STAMPS, TEE>), \
+#define WRP_FUSED_B_ATTR(TAPS, STAMPS, TEE, RAW)                                                                    \
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<TAPS, STAMPS, TEE, RAW>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES))
-    WRP_FUSED_B_ATTR(7, false, false); WRP_FUSED_B_ATTR(9, false, false);
-    WRP_FUSED_B_ATTR(7, true, false);  WRP_FUSED_B_ATTR(9, true, false);      // diagnostics: phase stamps
-    WRP_FUSED_B_ATTR(7, false, true);  WRP_FUSED_B_ATTR(9, false, true);      // diagnostics: the intermediate copied out
+    WRP_FUSED_B_ATTR(7, false, false, false); WRP_FUSED_B_ATTR(9, false, false, false);
+    WRP_FUSED_B_ATTR(7, false, false, true);  WRP_FUSED_B_ATTR(9, false, false, true);      // wire-format input
+    WRP_FUSED_B_ATTR(7, true, false, false);  WRP_FUSED_B_ATTR(9, true, false, false);      // diagnostics: phase stamps
+    WRP_FUSED_B_ATTR(7, false, true, false);  WRP_FUSED_B_ATTR(9, false, true, false);      // diagnostics: the intermediate copied out
+    WRP_FUSED_B_ATTR(7, false, true, true);   WRP_FUSED_B_ATTR(9, false, true, true);
 #undef WRP_FUSED_B_ATTR
     h->fused_armed = h->fused;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
@@ -1139,7 +1122,6 @@ int wrp_debug_fused_tee(wrp_handle h, const void *d_in, int raw, int n_sectors, 
 {
     if (!h || !d_in || !d_out || !d_tee || n_sectors < WRP_FUSED_MIN_SECTORS) return WRP_ERR_INVALID;
     if (!h->tuned && !h->tuned_b) return WRP_ERR_UNSUPPORTED;
-    if (raw && !h->tuned) return WRP_ERR_UNSUPPORTED;     // the wire format goes INTO the launch for m = 1024, n = 512 only
     const wrp_config &c = h->cfg;
     if (tee_bytes < sizeof(float2) * (size_t)n_sectors * c.channels * (c.m / 2) * c.n) return WRP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

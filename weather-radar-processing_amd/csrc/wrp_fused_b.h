@@ -61,33 +61,48 @@ constexpr int FUSED_B_INPUT_AUX = AUX_NT;
 // Request pacing (wrp_fused.h): 16 = one load at a time over the task, 1.69 us/sector, HBM traffic 1.13 x the algorithmic
 // bytes; 4 = four quarters, 1.74 us/sector, 1.06 x (the smoother stream leaves fewer non-temporal lines per L2 set to evict
 // in place of the slot's): profiles/r03/fused_b_input_policy.log, ab_request_pacing_B.log.
-template <int QUARTER>
-__device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
-                                                  float4 (&v)[16], float2 &wdv, bool valid)
+// RAW (wire-format input): src = the SECTOR's 12-byte samples (hhI hhQ vvI vvQ vhI vhQ, big-endian int16,
+// sector.cpp:52-62) + 4 ch bytes; the lane's two samples of a row are 24 contiguous bytes of which the 16 from byte 4 ch
+// on hold its channel's dword of the first sample in .x and of the second in .w (.y, .z: the dwords in between, never
+// used) -- ONE 16-byte load per row as in the planar form, the same sixteen requests per task, no decode pass.
+template <bool RAW>
+__device__ __forceinline__ void fused_b_tile_addr(const float2 *src, int col_base, bool valid, rsrc_t &rs, int &voff, int &row_stride)
 {
     const int w = wave_id();
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int p0 = w * 16 + (l >> 2), cp = l & 3;
-    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
-    const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
+    rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * (RAW ? 12u : 8u) : 0u);
+    voff = (p0 * RB_N + col_base + cp * 2) * (RAW ? 12 : 8);
+    row_stride = RB_N * (RAW ? 12 : 8);
+}
+template <int QUARTER, bool RAW = false>
+__device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
+                                                  float4 (&v)[16], float2 &wdv, bool valid)
+{
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int cp = l & 3;
+    rsrc_t rs;
+    int voff, row_stride;
+    fused_b_tile_addr<RAW>(src, col_base, valid, rs, voff, row_stride);
 #pragma unroll
-    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * r * RB_N * 8);
+    for (int r = QUARTER; r < 16; r += 4) v[r] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * r * row_stride);
     if (QUARTER == 3) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
 // ONE row load of the next tile (rows p0 + 128 R): the tile is requested a piece at a time over the task, see wrp_fused.h
-template <int R>
+template <int R, bool RAW = false>
 __device__ __forceinline__ void fused_b_tile_load1(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                    float4 (&v)[16], float2 &wdv, bool valid)
 {
-    const int w = wave_id();
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
-    const int p0 = w * 16 + (l >> 2), cp = l & 3;
-    const rsrc_t rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * 8u : 0u);
-    const int voff = (p0 * RB_N + col_base + cp * 2) * 8;
-    v[R] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * RB_N * 8);
+    const int cp = l & 3;
+    rsrc_t rs;
+    int voff, row_stride;
+    fused_b_tile_addr<RAW>(src, col_base, valid, rs, voff, row_stride);
+    v[R] = buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * R * row_stride);
     if (R == 15) wdv = buf_load_f2<0>(make_rsrc(wd, (unsigned)RB_N * 4u), (col_base + cp * 2) * 4, 0);
 }
 
@@ -104,7 +119,7 @@ __device__ __forceinline__ void fused_b_stage1_tables(const unsigned char *smem,
     rb_derive_twiddles(tw);
 }
 
-template <int COLUMN>
+template <int COLUMN, bool RAW = false>
 __device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const cf (&tw)[16], cf (&g)[8])
 {
     typedef FusedTileB T;
@@ -122,7 +137,8 @@ __device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
-        a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
+        if (RAW) a[r] = cscale(wire_sample(COLUMN ? v[r].w : v[r].x), wgt);   // exact conversion: bit-identical to decode_wire + the planar form
+        else a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
     }
     fft16<-1>(a);
     *reinterpret_cast<float2 *>(smem + slot) = a[0];
@@ -224,9 +240,9 @@ __device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, in
     }
 }
 
-template <int TAPS, bool STAMPS = false, bool TEE = false>
+template <int TAPS, bool STAMPS = false, bool TEE = false, bool RAW = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_2048x128(
-    const float2 *__restrict__ iq,   // [S][C][2048][128]
+    const float2 *__restrict__ iq,   // [S][C][2048][128]; RAW: the wire format, [S][2048 x 128][12 bytes]
     float *__restrict__ out,         // [S][1024][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS]: per team ONE slot [2 channels][512][128] through which both halves go
     FusedCtl *ctl, RangeConsts rc /* wr_c symmetric */, const float2 *__restrict__ tw_n /* exp(+2 pi i k / 128) */, int n_sectors,
@@ -281,13 +297,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         // halves of the same lines), so that a tile that loads slowly is a transient of every member instead of one member
         // that is late in every task (wrp_fused.h: tile_col)
         auto tile_col = [&](int q) { return (((rank & 15) + 2 * q) & 15) * 8; };
-        auto tile_src = [&](int q) { return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N; };
+        auto tile_src = [&](int q) {   // RAW: the sector's samples from byte 4 ch on (float2 units: 12 bytes = 1.5)
+            if (RAW) return reinterpret_cast<const float2 *>(reinterpret_cast<const unsigned char *>(iq) + (size_t)(trank + q * teams) * RB_M * RB_N * 12 + 4 * ch);
+            return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N;
+        };
         float4 v[16];
         float2 wdv;
-        fused_b_tile_load<0>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
-        fused_b_tile_load<1>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
-        fused_b_tile_load<2>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
-        fused_b_tile_load<3>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<0, RAW>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<1, RAW>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<2, RAW>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
+        fused_b_tile_load<3, RAW>(tile_src(0), tile_col(0), rc.wd, v, wdv, tasks > 0);
         for (int e = tid; e < RB_M / 2; e += FUSED_THREADS) {
             const int p0 = e >> 3, j = e & 7;
             *reinterpret_cast<float2 *>(smem + T::tw1_addr(p0, j)) = rc.tw[(p0 * (j + 1)) & (RB_M - 1)];
@@ -307,14 +326,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 cf tw[16];
                 stamp(q, 0);
                 fused_b_stage1_tables(smem, tw);
-                fused_b_stage1<0>(smem, v, wdv, tw, ga);
+                fused_b_stage1<0, RAW>(smem, v, wdv, tw, ga);
                 stamp(q, 5);
                 // half 1 of the previous task was stored half a stage ago: drained and counted here (see wrp_fused.h)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int last = 0;
                 if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
                 if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
-                fused_b_stage1<1>(smem, v, wdv, tw, gc);
+                fused_b_stage1<1, RAW>(smem, v, wdv, tw, gc);
             }
             __syncthreads();                    // A1: group 0 is in the image
             stamp(q, 1);
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             const bool more = q + 1 < tasks;
             const int col_base = tile_col(q), next_col = tile_col(q + 1);
             cf o[2][4];
-#define WRP_LB(R) fused_b_tile_load1<R>(next, next_col, rc.wd, v, wdv, more)
+#define WRP_LB(R) fused_b_tile_load1<R, RAW>(next, next_col, rc.wd, v, wdv, more)
             WRP_LB(0); WRP_LB(8);
             fused_b_stage2(smem);
             WRP_LB(4); WRP_LB(12);
