@@ -18,7 +18,9 @@
 //     so the two forms stay bit-identical) -- and the range window is kept as its first half (it is symmetric: the
 //     engine stores wr_c[i] = wr_c[m - 1 - i] exactly): 78,912 bytes, two workgroups per CU;
 //   * a row wave transforms FOUR rows at a time (16 lanes per row, 128 = 8 x 4 x 4: doppler_row_128), the HH and the
-//     VV row of two gates, so Zdb and Zdr leave with the task that produced them; every wave serves both halves.
+//     VV row of two gates, so Zdb and Zdr leave with the task that produced them; every wave serves both halves;
+//   * wire-format input (RAW instantiation): the tile members read the 12-byte samples themselves -- ONE
+//     16-byte load per lane and row as in the planar form (fused_b_tile_addr), byte swap + conversion in stage 1.
 #pragma once
 #include <hip/hip_runtime.h>
 
