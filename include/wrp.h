@@ -82,6 +82,13 @@ typedef struct {
 /* m = 2048, n = 128 (BASELINE configs[4]) has tuned kernels of its own (csrc/wrp_shape_b.h); this flag runs the
  * shape-generic radix-2 kernels instead (every other shape always does): parity tests and A/B */
 #define WRP_FLAG_GENERIC_KERNELS 0x8000
+/* Wire format of this handle's raw entries (wrp_pinned_raw_slot, wrp_submit_raw, wrp_process_batch_raw[_framed]_device,
+ * wrp_debug_fused_tee(raw)): 8 bytes per sample -- hhI hhQ vvI vvQ, big-endian int16 -- instead of 12: the sample of
+ * sector.cpp:52-62 without its VH pair (bytes 8..11), which no output reads (rpv2.cu:199-213).  The feeder drops those bytes
+ * in the copy it makes anyway (socket / file -> pinned slot: host/wire.h, wire_drop_vh): a third fewer PCIe bytes per sector
+ * (4 MiB instead of 6 at m = 1024, n = 512), and the slot path is PCIe-bound.  Results are bit-identical to the 12-byte
+ * entries on the same samples.  With channels = 3 the VH plane of the decoded block is left as it is (never read). */
+#define WRP_FLAG_WIRE_8 0x10000
 /* test hook: the fused launch is issued with half its workgroups, so that it must report (wrp_check)
  * that its teams are incomplete and the handle must fall back to the two kernels */
 #define WRP_FLAG_DEBUG_FUSED_UNDERSIZED 0x4000
@@ -130,7 +137,8 @@ int wrp_submit(wrp_handle h, int slot, int sector, int elevation);
  * (rpv2.cu:369-383, its "restructuring" milliseconds).  Here the caller copies the datagrams
  * as received -- m*n samples of 12 bytes: hhI hhQ vvI vvQ vhI vhQ, big-endian int16 -- into the
  * slot's pinned raw buffer (*bytes = m*n*12) and wrp_submit_raw uploads them (half the PCIe
- * bytes of the 3-plane fp32 block) and decodes on the GPU, bit-identically, before the chain. */
+ * bytes of the 3-plane fp32 block) and decodes on the GPU, bit-identically, before the chain.
+ * A handle created with WRP_FLAG_WIRE_8 takes 8-byte samples here (*bytes = m*n*8). */
 int wrp_pinned_raw_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes);
 int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation);
 
@@ -167,7 +175,8 @@ int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, floa
  * (3 MiB) of HBM reads per sector instead of 8 (4) and no decode pass.  Otherwise (small batches, other shapes,
  * WRP_FLAG_TWO_KERNELS, the repeat of a launch that gave up) the batch is decoded on the GPU, up to max_batch sectors at a
  * time, in front of the two kernels.  Results are bit-identical to Sector::fromByteArray + the scatter of
- * rpv2.cu:372-383 + wrp_process_batch_device. */
+ * rpv2.cu:372-383 + wrp_process_batch_device.  WRP_FLAG_WIRE_8: d_raw = [n_sectors][m*n samples][8 bytes] (4 / 2 MiB per
+ * sector); at m = 2048, n = 128 a tile member's bytes are then the planar form's (64 of every 1 KiB row). */
 int wrp_process_batch_raw_device(wrp_handle h, const void *d_raw, int n_sectors, float *d_out, void *stream);
 
 /* Egress framing for batches (rpv2.cu:631-661, read_single.cc:510-520).  The batch entries above with one
@@ -241,8 +250,8 @@ int wrp_debug_fused_mid(wrp_handle h, const void *d_iq, int n_sectors, float *d_
 
 /* Parity of the WHOLE intermediate: one fused launch (its diagnostics instantiation) whose tile workgroups also write
  * everything they put through the hand-over slots -- both halves of every task -- to d_tee, device memory,
- * [n_sectors][channels][m/2 gates][n] complex.  raw != 0: d_in is the wire format (12 bytes per sample) and the launch the
- * wire-format one.  Every [m/2][n] block must equal wrp_dump_stage(WRP_STAGE_MID) of that sector
+ * [n_sectors][channels][m/2 gates][n] complex.  raw != 0: d_in is the handle's wire format (12 or 8 bytes per sample) and the
+ * launch the wire-format one.  Every [m/2][n] block must equal wrp_dump_stage(WRP_STAGE_MID) of that sector
  * and channel bit for bit: the stage dumps come from the two-kernel path, this ties the launch the bench times to them
  * (rpv2.cu:409-502: the reference's intermediate after its range FFT).  Synchronous. */
 int wrp_debug_fused_tee(wrp_handle h, const void *d_in, int raw, int n_sectors, float *d_out, void *d_tee, size_t tee_bytes);

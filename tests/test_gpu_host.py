@@ -21,8 +21,10 @@ def wire_bytes(iq):
     return s.tobytes()
 
 
-@pytest.mark.parametrize("streams", [1, 3])
-def test_rpv2_file_replay(tmp_path, oracle, streams):
+@pytest.mark.parametrize("streams,wire8", [(1, False), (3, False), (2, True)])
+def test_rpv2_file_replay(tmp_path, oracle, streams, wire8):
+    """wire8: the file holds the reference's 12-byte samples either way; --wire8 makes the feeder drop VH on the way into the
+    pinned slot (WRP_FLAG_WIRE_8) -- same frames."""
     assert os.path.exists(RPV2), "run `make host`"
     K = 5
     sectors = [oracle.synthetic_sector(s) for s in range(K)]
@@ -30,7 +32,7 @@ def test_rpv2_file_replay(tmp_path, oracle, streams):
     with open(fin, "wb") as f:
         for iq in sectors:
             f.write(wire_bytes(iq))
-    r = subprocess.run([RPV2, str(streams), "--in", f"file:{fin}", "--out", f"file:{fout}", "--sectors", str(K)],
+    r = subprocess.run([RPV2, str(streams), "--in", f"file:{fin}", "--out", f"file:{fout}", "--sectors", str(K)] + (["--wire8"] if wire8 else []),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert f"{K} sectors processed" in r.stderr
@@ -187,9 +189,10 @@ def test_rpv2_host_fill_source_and_process_entry_point():
     import re
     proc = os.path.join(os.path.dirname(RPV2), "process")
     assert os.path.exists(proc) and os.path.samefile(os.path.realpath(proc), RPV2), "run `make process`"
-    for exe, devices, threads, want in ((RPV2, "0", 1, 12), (proc, "0,0", 3, 24)):
+    for exe, devices, threads, want, extra in ((RPV2, "0", 1, 12, []), (proc, "0,0", 3, 24, []), (RPV2, "0", 4, 12, ["--wire8"])):
         r = subprocess.run([exe, "2", "--devices", devices, "--in", f"synthetic:copy:{threads}", "--bind-numa", "--out", "none",
-                            "--scan", "6,2", "--sectors", "12"], capture_output=True, text=True, timeout=120)
+                            "--scan", "6,2", "--sectors", "12"] + extra, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         m = re.search(r"rpv2: (\d+) sectors processed .*host fill by (\d+) thread", r.stderr)
         assert m and int(m.group(1)) == want and int(m.group(2)) == threads, r.stderr       # --sectors counts per GPU thread here
+        assert ("VH dropped" in r.stderr) == bool(extra)

@@ -110,3 +110,20 @@ def test_tcp_endpoints_echo_acknowledged_messages(host):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     assert host.wrph_tcp_loopback(port, 2, 3 << 20) == 0           # 3 MiB: needs many reads / writes
+
+
+def test_wire_drop_vh_is_the_12_byte_sample_without_bytes_8_to_11(host):
+    """WRP_FLAG_WIRE_8's feeder side (host/wire.h): the copy into the pinned slot keeps hhI hhQ vvI vvQ of every 12-byte
+    sample of sector.cpp:52-62 as they are and drops vhI vhQ -- the shuffled form, the plain loop and the FillPool's split
+    over threads, at sizes around the vector width and the threads' chunk boundaries."""
+    rng = np.random.default_rng(8)
+    host.wrph_wire_drop_vh.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    host.wrph_wire_drop_vh.restype = None
+    for samples in (0, 1, 3, 4, 5, 511, 512, 513, 2048 * 3 + 7, 1024 * 512):
+        src = rng.integers(0, 256, samples * 12 + 16, dtype=np.uint8)          # (slack: nothing behind the last sample is read as a sample)
+        want = src[:samples * 12].reshape(samples, 12)[:, :8].ravel()
+        for threads, portable in ((1, 1), (1, 0), (2, 0), (5, 0)):
+            dst = np.full(samples * 8 + 32, 0xA5, np.uint8)
+            host.wrph_wire_drop_vh(dst.ctypes.data, src.ctypes.data, samples, threads, portable)
+            assert np.array_equal(dst[:samples * 8], want), (samples, threads, portable)
+            assert (dst[samples * 8:] == 0xA5).all(), (samples, threads, portable)      # nothing written behind the last sample

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--shape", choices=["A", "B"], default="A")
     ap.add_argument("--no-check", action="store_true", help="timing-only builds whose results are wrong on purpose")
     ap.add_argument("--wire", action="store_true", help="time wrp_process_batch_raw_device (wire-format input) instead")
+    ap.add_argument("--wire8", action="store_true", help="... with 8-byte samples (WRP_FLAG_WIRE_8)")
     args = ap.parse_args()
 
     import numpy as np
@@ -49,7 +50,7 @@ def main():
     for path in args.libs:
         B._LIB = None
         B.lib_path = (lambda p: (lambda: p))(os.path.abspath(path))     # the binding's loader, pointed at this build
-        e = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, m=m, n=n)
+        e = wrp_amd.Engine(device=0, n_slots=1, n_sectors=1, n_elevations=1, m=m, n=n, flags=wrp_amd.FLAG_WIRE_8 if args.wire8 else 0)
         e.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
         torch.cuda.synchronize()
         got = d_out.cpu().numpy()
@@ -62,9 +63,9 @@ def main():
                   + ("" if same else f" (max |diff| {np.nanmax(np.abs(first - got)):.3g})"))
         engines.append((os.path.basename(path), e, ok, []))
     k = 1e3 / (args.iters * S)
-    if args.wire:
+    if args.wire or args.wire8:
         import time
-        w = np.zeros((4, m * n, 6), dtype=">i2")
+        w = np.zeros((4, m * n, 4 if args.wire8 else 6), dtype=">i2")
         for q in range(4):
             for c in range(2):
                 w[q, :, 2 * c] = pool[q][c].real.ravel()

@@ -14,6 +14,7 @@ from .binding import (  # noqa: F401
     FLAG_GENERIC_KERNELS,
     FLAG_ONE_TILE_PER_BLOCK,
     FLAG_TWO_KERNELS,
+    FLAG_WIRE_8,
     FUSED_MIN_SECTORS,
     WrpConfig,
     WrpError,

@@ -27,6 +27,7 @@ class WrpConfig(C.Structure):
 
 
 FLAG_ONE_TILE_PER_BLOCK, FLAG_TWO_KERNELS, FLAG_DEBUG_FUSED_UNDERSIZED, FLAG_GENERIC_KERNELS = 0x400, 0x800, 0x4000, 0x8000
+FLAG_WIRE_8 = 0x10000     # the handle's raw entries take 8-byte samples (hh, vv; VH dropped by the feeder)
 FUSED_MIN_SECTORS = 8
 
 STAGE_IDS = {"01hamm": 1, "02fft1": 2, "03fft2-noshift": 3, "03fft2": 4, "04abs": 5, "08pow": 6, "rowsum": 7, "mid": 8}
@@ -212,7 +213,7 @@ class Engine:
         return np.frombuffer(buf, dtype=np.complex64).reshape(self.channels, self.m, self.n)
 
     def raw_slot_array(self, slot):
-        """numpy view [m*n*12] uint8 of the slot's pinned wire-format buffer (sector.cpp:52-62 layout)."""
+        """numpy view [m*n*12] uint8 (FLAG_WIRE_8: [m*n*8]) of the slot's pinned wire-format buffer (sector.cpp:52-62 layout)."""
         p, nbytes = C.c_void_p(), C.c_size_t()
         self._check(self.lib.wrp_pinned_raw_slot(self._h, slot, C.byref(p), C.byref(nbytes)), "wrp_pinned_raw_slot")
         buf = (C.c_char * nbytes.value).from_address(p.value)

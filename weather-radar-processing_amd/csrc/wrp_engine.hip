@@ -33,7 +33,7 @@ struct Slot {
     float2 *d_mid = nullptr;  // device [2][m/2][n]
     float *d_out = nullptr;   // device [m/2][2]
     unsigned *d_frames = nullptr;   // device [2][1 + m/2]: the two products framed for the wire (N2)
-    unsigned char *h_raw = nullptr;   // pinned [m*n][12] wire bytes (allocated on first use)
+    unsigned char *h_raw = nullptr;   // pinned [m*n][wire_bytes] wire bytes (allocated on first use)
     unsigned char *d_raw = nullptr;
     hipEvent_t done = nullptr;
     bool busy = false;
@@ -72,6 +72,7 @@ struct wrp_engine {
     wrp::MaTaps taps;
     int taps_pad = 7;
     bool tuned = true;        // m = 1024, n = 512: tuned kernels; otherwise wrp_generic.h
+    int wire_bytes = 12;      // bytes per sample of the raw entries: 12 (sector.cpp:52-62), or 8 with WRP_FLAG_WIRE_8 (VH dropped by the feeder)
     bool tuned_b = false;     // m = 2048, n = 128 (BASELINE configs[4]): wrp_shape_b.h; its stage dumps come from wrp_generic.h
     bool persist = false;     // range pass as a fixed grid walking the tiles with prefetch
     int range_tcols = 16;     // column tile of the range pass (tuning: cfg.flags & 0xff)
@@ -302,18 +303,24 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
     // two workgroups per CU; the test flag launches one per CU, so that no team gets its row members
     const int grid = (c.flags & WRP_FLAG_DEBUG_FUSED_UNDERSIZED) ? h->n_cus : h->n_cus * 2;
     const int form = d_tee ? 2 : d_stamps ? 1 : 0;      // which instantiation
+    const int wb = raw ? h->wire_bytes : 0;             // 0: the planar block; 12 / 8: bytes per wire sample
+    const bool t7 = h->taps_pad == 7;
     if (h->tuned_b) {
 #define WRP_FUSED_B(TAPS, STAMPS, TEE, RAW)                                                                           \
     hipLaunchKernelGGL((wrp::fused_chain_2048x128<TAPS, STAMPS, TEE, RAW>), dim3(grid), dim3(wrp::FUSED_THREADS),     \
                        wrp::FusedTileB::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
                        fr.frames, fr.hdrs, d_tee)
-        if (raw) {   // the wire format straight into the tile workgroups
-            if (form == 2) { if (h->taps_pad == 7) WRP_FUSED_B(7, false, true, true); else WRP_FUSED_B(9, false, true, true); }
-            else { if (h->taps_pad == 7) WRP_FUSED_B(7, false, false, true); else WRP_FUSED_B(9, false, false, true); }
-        } else if (form == 2) { if (h->taps_pad == 7) WRP_FUSED_B(7, false, true, false); else WRP_FUSED_B(9, false, true, false); }
-        else if (form == 1) { if (h->taps_pad == 7) WRP_FUSED_B(7, true, false, false); else WRP_FUSED_B(9, true, false, false); }
-        else { if (h->taps_pad == 7) WRP_FUSED_B(7, false, false, false); else WRP_FUSED_B(9, false, false, false); }
+#define WRP_FUSED_B_FORMS(RAW)                                                                                        \
+    do {                                                                                                              \
+        if (form == 2) { if (t7) WRP_FUSED_B(7, false, true, RAW); else WRP_FUSED_B(9, false, true, RAW); }           \
+        else { if (t7) WRP_FUSED_B(7, false, false, RAW); else WRP_FUSED_B(9, false, false, RAW); }                   \
+    } while (0)
+        if (wb == 12) WRP_FUSED_B_FORMS(12);      // the wire format straight into the tile workgroups
+        else if (wb == 8) WRP_FUSED_B_FORMS(8);
+        else if (form == 1) { if (t7) WRP_FUSED_B(7, true, false, 0); else WRP_FUSED_B(9, true, false, 0); }
+        else WRP_FUSED_B_FORMS(0);
+#undef WRP_FUSED_B_FORMS
 #undef WRP_FUSED_B
         HIP_TRY(h, hipGetLastError());
         return WRP_OK;
@@ -323,16 +330,16 @@ int launch_fused(wrp_engine *h, FusedLane &lane, const float2 *d_iq, int n_secto
                        wrp::FusedTile::LDS_BYTES, st, d_iq, d_out, lane.d_pool, lane.d_ctl, rc, h->d_tw_n_arr, n_sectors, \
                        c.channels, h->taps, c.k_range_resolution, c.k_calibration, h->d_status + slot, d_stamps,      \
                        fr.frames, fr.hdrs, d_tee)
-    if (raw) {   // the wire format straight into the tile workgroups
-        if (form == 2) { if (h->taps_pad == 7) WRP_FUSED(7, false, true, true); else WRP_FUSED(9, false, true, true); }
-        else { if (h->taps_pad == 7) WRP_FUSED(7, false, true, false); else WRP_FUSED(9, false, true, false); }
-    } else if (form == 2) {
-        if (h->taps_pad == 7) WRP_FUSED(7, false, false, true); else WRP_FUSED(9, false, false, true);
-    } else if (form == 1) {
-        if (h->taps_pad == 7) WRP_FUSED(7, true, false, false); else WRP_FUSED(9, true, false, false);
-    } else {
-        if (h->taps_pad == 7) WRP_FUSED(7, false, false, false); else WRP_FUSED(9, false, false, false);
-    }
+#define WRP_FUSED_FORMS(RAW)                                                                                          \
+    do {                                                                                                              \
+        if (form == 2) { if (t7) WRP_FUSED(7, false, RAW, true); else WRP_FUSED(9, false, RAW, true); }               \
+        else { if (t7) WRP_FUSED(7, false, RAW, false); else WRP_FUSED(9, false, RAW, false); }                       \
+    } while (0)
+    if (wb == 12) WRP_FUSED_FORMS(12);            // the wire format straight into the tile workgroups
+    else if (wb == 8) WRP_FUSED_FORMS(8);
+    else if (form == 1) { if (t7) WRP_FUSED(7, true, 0, false); else WRP_FUSED(9, true, 0, false); }
+    else WRP_FUSED_FORMS(0);
+#undef WRP_FUSED_FORMS
 #undef WRP_FUSED
     HIP_TRY(h, hipGetLastError());
     return WRP_OK;
@@ -394,11 +401,15 @@ int ensure_decode(wrp_engine *h, int sectors)
     h->decode_cap = sectors;
     return WRP_OK;
 }
-void launch_decode(wrp_engine *h, const unsigned char *raw, int cnt, hipStream_t st, const unsigned *gate = nullptr)
+// cnt sectors of wire bytes -> planar blocks at `dst`
+void launch_decode(wrp_engine *h, const unsigned char *raw, float2 *dst, int cnt, hipStream_t st, const unsigned *gate = nullptr)
 {
     const int count = h->cfg.m * h->cfg.n;
-    hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256, cnt), dim3(256), 0, st, (const unsigned *)raw, h->d_decode, count,
-                       h->cfg.channels, gate);
+    const dim3 grid((count + 255) / 256, cnt), block(256);
+    if (h->wire_bytes == 8)
+        hipLaunchKernelGGL(wrp::decode_wire<8>, grid, block, 0, st, (const unsigned *)raw, dst, count, h->cfg.channels, gate);
+    else
+        hipLaunchKernelGGL(wrp::decode_wire<12>, grid, block, 0, st, (const unsigned *)raw, dst, count, h->cfg.channels, gate);
 }
 
 // a wire-format batch on the two-kernel path: decode_wire + the two kernels, as many sectors at a time as both workspaces hold
@@ -411,7 +422,7 @@ int launch_two_kernel_raw_batch(wrp_engine *h, const unsigned char *raw, int n_s
     if (rc == WRP_OK) rc = workspace_acquire(h, st);
     for (int s0 = 0; rc == WRP_OK && s0 < n_sectors; s0 += h->decode_cap) {
         const int cnt = std::min(h->decode_cap, n_sectors - s0);    // decode_cap <= max_batch: d_mid holds them too
-        launch_decode(h, raw + (size_t)s0 * count * 12, cnt, st, gate);
+        launch_decode(h, raw + (size_t)s0 * count * h->wire_bytes, h->d_decode, cnt, st, gate);
         rc = launch_chain(h, h->d_decode, cnt, h->d_mid, d_out + (size_t)s0 * (c.m / 2) * 2, st, nullptr, nullptr, 0,
                           frames_at(fr, c, s0), gate);
     }
@@ -577,6 +588,7 @@ int create_impl(wrp_engine *h)
     // up to 144 KiB of dynamic LDS for the range pass
     h->range_tcols = (c.flags & 0xff) == 16 ? 16 : 8;   // default chosen below
     h->tuned = shape_tuned(c.m, c.n);
+    h->wire_bytes = (c.flags & WRP_FLAG_WIRE_8) ? 8 : 12;
     h->tuned_b = c.m == wrp::RB_M && c.n == wrp::RB_N && (c.flags & WRP_FLAG_GENERIC_KERNELS) == 0;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::range_pass_2048),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::RangeTileB::LDS_BYTES));
@@ -585,11 +597,13 @@ int create_impl(wrp_engine *h)
 #define WRP_FUSED_B_ATTR(TAPS, STAMPS, TEE, RAW)                                                                    \
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_2048x128<TAPS, STAMPS, TEE, RAW>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTileB::LDS_BYTES))
-    WRP_FUSED_B_ATTR(7, false, false, false); WRP_FUSED_B_ATTR(9, false, false, false);
-    WRP_FUSED_B_ATTR(7, false, false, true);  WRP_FUSED_B_ATTR(9, false, false, true);      // wire-format input
-    WRP_FUSED_B_ATTR(7, true, false, false);  WRP_FUSED_B_ATTR(9, true, false, false);      // diagnostics: phase stamps
-    WRP_FUSED_B_ATTR(7, false, true, false);  WRP_FUSED_B_ATTR(9, false, true, false);      // diagnostics: the intermediate copied out
-    WRP_FUSED_B_ATTR(7, false, true, true);   WRP_FUSED_B_ATTR(9, false, true, true);
+    WRP_FUSED_B_ATTR(7, false, false, 0);  WRP_FUSED_B_ATTR(9, false, false, 0);
+    WRP_FUSED_B_ATTR(7, false, false, 12); WRP_FUSED_B_ATTR(9, false, false, 12);     // wire-format input
+    WRP_FUSED_B_ATTR(7, false, false, 8);  WRP_FUSED_B_ATTR(9, false, false, 8);      // ... without VH (WRP_FLAG_WIRE_8)
+    WRP_FUSED_B_ATTR(7, true, false, 0);   WRP_FUSED_B_ATTR(9, true, false, 0);       // diagnostics: phase stamps
+    WRP_FUSED_B_ATTR(7, false, true, 0);   WRP_FUSED_B_ATTR(9, false, true, 0);       // diagnostics: the intermediate copied out
+    WRP_FUSED_B_ATTR(7, false, true, 12);  WRP_FUSED_B_ATTR(9, false, true, 12);
+    WRP_FUSED_B_ATTR(7, false, true, 8);   WRP_FUSED_B_ATTR(9, false, true, 8);
 #undef WRP_FUSED_B_ATTR
     h->fused_armed = h->fused;
     h->persist = h->tuned && (c.flags & WRP_FLAG_ONE_TILE_PER_BLOCK) == 0;
@@ -610,11 +624,13 @@ int create_impl(wrp_engine *h)
 #define WRP_FUSED_ATTR(TAPS, STAMPS, RAW, TEE)                                                                      \
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&wrp::fused_chain_1024x512<TAPS, STAMPS, RAW, TEE>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, wrp::FusedTile::LDS_BYTES))
-    WRP_FUSED_ATTR(7, false, false, false); WRP_FUSED_ATTR(9, false, false, false);     // the launch
-    WRP_FUSED_ATTR(7, false, true, false);  WRP_FUSED_ATTR(9, false, true, false);      // wire-format input
-    WRP_FUSED_ATTR(7, true, false, false);  WRP_FUSED_ATTR(9, true, false, false);      // diagnostics: phase stamps
-    WRP_FUSED_ATTR(7, false, false, true);  WRP_FUSED_ATTR(9, false, false, true);      // diagnostics: the intermediate copied out
-    WRP_FUSED_ATTR(7, false, true, true);   WRP_FUSED_ATTR(9, false, true, true);
+    WRP_FUSED_ATTR(7, false, 0, false);  WRP_FUSED_ATTR(9, false, 0, false);      // the launch
+    WRP_FUSED_ATTR(7, false, 12, false); WRP_FUSED_ATTR(9, false, 12, false);     // wire-format input
+    WRP_FUSED_ATTR(7, false, 8, false);  WRP_FUSED_ATTR(9, false, 8, false);      // ... without VH (WRP_FLAG_WIRE_8)
+    WRP_FUSED_ATTR(7, true, 0, false);   WRP_FUSED_ATTR(9, true, 0, false);       // diagnostics: phase stamps
+    WRP_FUSED_ATTR(7, false, 0, true);   WRP_FUSED_ATTR(9, false, 0, true);       // diagnostics: the intermediate copied out
+    WRP_FUSED_ATTR(7, false, 12, true);  WRP_FUSED_ATTR(9, false, 12, true);
+    WRP_FUSED_ATTR(7, false, 8, true);   WRP_FUSED_ATTR(9, false, 8, true);
 #undef WRP_FUSED_ATTR
     HIP_TRY(h, hipEventCreateWithFlags(&h->lane.done, hipEventDisableTiming));
     HIP_TRY(h, hipMalloc(&h->lane.d_ctl, sizeof(wrp::FusedCtl)));
@@ -716,7 +732,7 @@ int wrp_create(const wrp_config *cfg, int device, wrp_handle *out)
     *out = nullptr;
     if (cfg->m <= 0 || cfg->n <= 0 || cfg->n_slots < 1 || cfg->n_slots > 64 || cfg->n_sectors < 1 ||
         cfg->n_elevations < 1 || cfg->ma_count < 1 || cfg->ma_count > 9 || cfg->max_batch < 0 ||
-        (cfg->flags & ~(0xff | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED | WRP_FLAG_GENERIC_KERNELS)) != 0 ||
+        (cfg->flags & ~(0xff | WRP_FLAG_TWO_KERNELS | WRP_FLAG_ONE_TILE_PER_BLOCK | WRP_FLAG_DEBUG_FUSED_UNDERSIZED | WRP_FLAG_GENERIC_KERNELS | WRP_FLAG_WIRE_8)) != 0 ||
         ((cfg->flags & 0xff) != 0 && (cfg->flags & 0xff) != 8 && (cfg->flags & 0xff) != 16) || (cfg->channels != 2 && cfg->channels != 3) || device < 0)
         return WRP_ERR_INVALID;
     if (!shape_supported(cfg->m, cfg->n)) return WRP_ERR_UNSUPPORTED;
@@ -785,7 +801,7 @@ int wrp_pinned_raw_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes)
 {
     if (!h || slot < 0 || slot >= (int)h->slots.size() || !host_ptr) return WRP_ERR_INVALID;
     Slot &s = h->slots[slot];
-    const size_t nbytes = (size_t)h->cfg.m * h->cfg.n * 12;
+    const size_t nbytes = (size_t)h->cfg.m * h->cfg.n * h->wire_bytes;
     if (!s.h_raw) {
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipHostMalloc(&s.h_raw, nbytes, hipHostMallocDefault));
@@ -806,9 +822,8 @@ int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation)
     const wrp_config &c = h->cfg;
     const int count = c.m * c.n;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(s.d_raw, s.h_raw, (size_t)count * 12, hipMemcpyHostToDevice, s.stream));
-    hipLaunchKernelGGL(wrp::decode_wire, dim3((count + 255) / 256), dim3(256), 0, s.stream,
-                       (const unsigned *)s.d_raw, s.d_iq, count, c.channels, (const unsigned *)nullptr);
+    HIP_TRY(h, hipMemcpyAsync(s.d_raw, s.h_raw, (size_t)count * h->wire_bytes, hipMemcpyHostToDevice, s.stream));
+    launch_decode(h, s.d_raw, s.d_iq, 1, s.stream);
     int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr, s.d_frames, frame_header_word(sector, elevation));
     if (rc != WRP_OK) return rc;
     float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;

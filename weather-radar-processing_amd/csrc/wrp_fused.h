@@ -233,6 +233,32 @@ __device__ __forceinline__ void spin_flags_sticky(const FusedFlags *line, unsign
     failed |= budget == 0;   // straight-line code here; the caller reports `failed` once, after its loop
 }
 
+// ---- the slow lines of the input, touched ahead by the row waves ---------------------------------------------------
+// Of the eight 128-byte lines of every KiB of device memory the one at byte 384 is slow to read -- 9.3 us against 7.05 for
+// a column tile of the 2048 x 128 launch that falls on it, 4.0 against 3.25 when the caches serve it; it moves with the
+// ABSOLUTE address, not with the buffer (tools/linebench.hip, profiles/r04/linebench.log) -- and a team moves at the pace
+// of the member whose tile lies on it (profiles/r04/fused_b_slow_line.log).  The row waves stand at their polls for half
+// of every task: each of them touches its share of those lines of the input the tile members will ask for NEXT task (one
+// dword per line, default cache policy, so that the line waits in the XCD's L2; an eighth of the input, 512 KiB per task
+// and team), and the members on the slow tile then find L2 hits: 2048 x 128 launch 1.52 -> 1.30 us/sector (-14 %,
+// profiles/r05/ab_b_slow_line_touch.log; wrp_fused_b.h).  In the 1024 x 512 launch a slow tile is a sixteenth of a member's
+// requests of a task, not all of them, and the touches gain nothing (-0.5 +- 0.3 %; wire format +3.7 %:
+// profiles/r05/ab_a_slow_line_touch.log): not used there.  The value is returned so that the caller can keep its register
+// reserved until a later s_waitcnt vmcnt(0) of its own has passed (nothing reads it).
+constexpr unsigned FUSED_SLOW_LINE = 384u;      // byte offset of the slow line in every KiB of the address space
+__device__ __forceinline__ float fused_touch_slow_lines(const void *range /* wave-uniform */, unsigned range_bytes, int wave_in_team,
+                                                        int l, bool valid)
+{
+    const unsigned first = (FUSED_SLOW_LINE - (unsigned)(unsigned long long)range) & 1023u;   // first byte of the range on a slow line
+    asm volatile("" : "+v"(l));
+    // lane k < 16 of wave w: the line 256 k + w of the range (a 4 MiB range has 4096 of them); everything else falls
+    // outside the descriptor and is dropped by the hardware
+    const unsigned line = 256u * (unsigned)(l & 15) + (unsigned)wave_in_team;
+    const unsigned voff = (l & 63) < 16 ? first + 1024u * line : 0x7ffffff0u;
+    const rsrc_t rs = make_rsrc(range, valid ? range_bytes : 0u);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+}
+
 // ---- tile member: device functions -----------------------------------------------------------
 // A QUARTER of this lane's 16 row loads: rows p0 + 64 r with r = QUARTER mod 4 (r = QUARTER, + 4, + 8,
 // + 12: exactly the inputs of ONE first-level butterfly of the radix-16 stage, so stage 1 can start
@@ -301,6 +327,14 @@ __device__ __forceinline__ void fused_stage1_tables(const unsigned char *smem, F
 __device__ __forceinline__ cf wire_sample(float bits)
 {
     const unsigned t = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, bits), __builtin_bit_cast(unsigned, bits), 0x02030001u);   // swap the bytes of both halves
+    return make_float2((float)(short)(t & 0xffffu), (float)(short)(t >> 16));
+}
+// the same for a sample whose HH and VV dwords lie in two registers: `sel` (wave-uniform) picks the channel in the byte
+// permute that swaps the bytes anyway -- WIRE_SEL_HH: bytes of hh (S0 of v_perm_b32), WIRE_SEL_VV: bytes of vv (S1)
+constexpr unsigned WIRE_SEL_HH = 0x06070405u, WIRE_SEL_VV = 0x02030001u;
+__device__ __forceinline__ cf wire_sample2(float hh_bits, float vv_bits, unsigned sel)
+{
+    const unsigned t = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hh_bits), __builtin_bit_cast(unsigned, vv_bits), sel);
     return make_float2((float)(short)(t & 0xffffu), (float)(short)(t >> 16));
 }
 template <int COLUMN>   // 0: the lane's first column (v[r].xy), 1: its second (v[r].zw)
@@ -545,7 +579,7 @@ __device__ __forceinline__ void fused_leave(FusedCtl *ctl, unsigned *host_status
 // HBM: 6 MiB per sector instead of 8, and no decode pass (6 MiB read + 8 MiB written + 8 MiB read again).
 // ONE piece of the wire-format tile: the rows pq + 64 RR and pq + 32 + 64 RR (sixteen pieces, requested one at a time:
 // eight in each of the sector's two tasks)
-template <int RR>
+template <int RR, int WB>
 __device__ __forceinline__ void fused_raw_tile_load1(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
                                                      float2 (&v)[32], float &wdv, bool valid)
 {
@@ -553,16 +587,16 @@ __device__ __forceinline__ void fused_raw_tile_load1(const unsigned *sector_raw 
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int pq = w * 4 + (l >> 4), c = l & 15;
-    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * 12u : 0u);
-    const int voff = (pq * DP_N + col_base + c) * 12;
-    v[2 * RR] = buf_load_f2<AUX_NT>(rs, voff, 64 * RR * DP_N * 12);
-    v[2 * RR + 1] = buf_load_f2<AUX_NT>(rs, voff, (64 * RR + 32) * DP_N * 12);
+    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * WB : 0u);
+    const int voff = (pq * DP_N + col_base + c) * WB;
+    v[2 * RR] = buf_load_f2<AUX_NT>(rs, voff, 64 * RR * DP_N * WB);
+    v[2 * RR + 1] = buf_load_f2<AUX_NT>(rs, voff, (64 * RR + 32) * DP_N * WB);
     if (RR == 15) {
         const float4 f = buf_load_f4<0>(make_rsrc(wd, (unsigned)DP_N * 4u), ((col_base + c) & ~3) * 4, 0);
         wdv = (c & 3) == 0 ? f.x : (c & 3) == 1 ? f.y : (c & 3) == 2 ? f.z : f.w;
     }
 }
-template <int QUARTER>
+template <int QUARTER, int WB>
 __device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /* wave-uniform */, int col_base, const float *wd,
                                                     float2 (&v)[32], float &wdv, bool valid)
 {
@@ -570,12 +604,12 @@ __device__ __forceinline__ void fused_raw_tile_load(const unsigned *sector_raw /
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int pq = w * 4 + (l >> 4), c = l & 15;
-    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * 12u : 0u);
-    const int voff = (pq * DP_N + col_base + c) * 12;
+    const rsrc_t rs = make_rsrc(sector_raw, valid ? (unsigned)RP_M * DP_N * WB : 0u);
+    const int voff = (pq * DP_N + col_base + c) * WB;
 #pragma unroll
     for (int rr = QUARTER; rr < 16; rr += 4) {   // rows pq + 64 rr (item 0) and pq + 32 + 64 rr (item 1)
-        v[2 * rr] = buf_load_f2<AUX_NT>(rs, voff, 64 * rr * DP_N * 12);
-        v[2 * rr + 1] = buf_load_f2<AUX_NT>(rs, voff, (64 * rr + 32) * DP_N * 12);
+        v[2 * rr] = buf_load_f2<AUX_NT>(rs, voff, 64 * rr * DP_N * WB);
+        v[2 * rr + 1] = buf_load_f2<AUX_NT>(rs, voff, (64 * rr + 32) * DP_N * WB);
     }
     if (QUARTER == 3) {   // the lane's Doppler-window value out of an aligned 16-byte load (element-wise use of a narrower
                           // buffer load's result is miscompiled by this hipcc: see buf_load_f4)
@@ -644,23 +678,24 @@ __device__ __forceinline__ void fused_raw_group1_to_lds(unsigned char *smem, con
 // The moves are written as instructions: left to the register allocator (`vv[r] = v[r].y`, it inserts the same 32
 // copies) the launch is 1.3 % slower.  Eight pieces on the points 0 1 2 3 | 5 | 6 7 9 of a task's eleven; seven other
 // placements +0.0 ... +5.5 % (ab_wire_request_schedules.log).
+template <int WB>   // bytes per wire sample: 12, or 8 (VH dropped by the feeder: the 16 lanes of a row segment then cover ONE 128-byte line)
 __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const unsigned *raw, float2 *mid, FusedCtl *ctl,
                                                       const RangeConsts &rc, int xcc, int rank, int teams, int trank, int tasks,
-                                                      float2 *tee /* diagnostics: see fused_store */)
+                                                      int channels, float2 *tee /* diagnostics: see fused_store; [S][channels][512][512] */)
 {
     typedef FusedTile T;
     const int tid = threadIdx.x, w = wave_id(), l = tid & 63;
     // the tile of a sector (both its tasks): rotated from sector to sector as in the planar launch
     auto tile_col = [&](int sec) { return ((rank + sec) & (FUSED_MEMBERS - 1)) * 16; };
-    auto sector_src = [&](int sec) { return raw + (size_t)(trank + sec * teams) * RP_M * DP_N * 3; };
+    auto sector_src = [&](int sec) { return raw + (size_t)(trank + sec * teams) * RP_M * DP_N * (WB / 4); };
     const int sectors = tasks >> 1;
     float2 v[32];     // the landing pairs: (hh, vv) dwords of the rows pq + 32 r
     float vv[32];     // the VV dwords of the sector in work, moved out of the pairs behind task HH's stage 1
     float wdv;
-    fused_raw_tile_load<0>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
-    fused_raw_tile_load<1>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
-    fused_raw_tile_load<2>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
-    fused_raw_tile_load<3>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<0, WB>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<1, WB>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<2, WB>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
+    fused_raw_tile_load<3, WB>(sector_src(0), tile_col(0), rc.wd, v, wdv, sectors > 0);
     for (int e = tid; e < RP_M; e += FUSED_THREADS) {
         const int p0 = e >> 4, k1 = e & 15;
         *reinterpret_cast<float2 *>(smem + T::tw1_addr(p0, k1)) = rc.tw[(p0 * k1) & (RP_M - 1)];
@@ -683,7 +718,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
     // one channel-task; it requests eight of the next sector's sixteen pieces (valid = false behind the last sector)
     auto task = [&](auto chc, int q, int col, const unsigned *next, int next_col, bool more) {
         constexpr int CH = decltype(chc)::value;
-        float2 *tee_task = tee ? tee + ((size_t)(trank + (q >> 1) * teams) * 2 + CH) * (RP_M / 2) * DP_N : nullptr;
+        float2 *tee_task = tee ? tee + ((size_t)(trank + (q >> 1) * teams) * channels + CH) * (RP_M / 2) * DP_N : nullptr;
         cf ga[8], gc[8];
         if (CH == 0) {
             float hh[32];
@@ -701,7 +736,7 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
         }
         __syncthreads();                    // A1
         cf o[2][4];
-#define WRP_LR(K) fused_raw_tile_load1<8 * CH + (K)>(next, next_col, rc.wd, v, wdv, more)
+#define WRP_LR(K) fused_raw_tile_load1<8 * CH + (K), WB>(next, next_col, rc.wd, v, wdv, more)
         WRP_LR(0);
         fused_stage2_item<0, false>(smem);
         WRP_LR(4);
@@ -757,9 +792,9 @@ __device__ __forceinline__ void fused_raw_tile_member(unsigned char *smem, const
 #else
 #define WRP_NO_DS_MERGE
 #endif
-template <int TAPS, bool STAMPS, bool RAW = false, bool TEE = false>
+template <int TAPS, bool STAMPS, int RAW = 0 /* wire-format input: bytes per sample (12 or 8), 0 = the planar block */, bool TEE = false>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) WRP_NO_DS_MERGE void fused_chain_1024x512(
-    const float2 *__restrict__ iq,   // [S][C][1024][512]; RAW: the wire format, [S][1024 x 512][12 bytes]
+    const float2 *__restrict__ iq,   // [S][C][1024][512]; RAW: the wire format, [S][1024 x 512][RAW bytes]
     float *__restrict__ out,         // [S][512][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS] per team: ONE slot[256][512] through which both halves go
     FusedCtl *ctl, RangeConsts rc, const float2 *__restrict__ tw_n, int n_sectors, int channels, MaTaps taps,
@@ -811,8 +846,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         }
     };
 
-    if (RAW && kind == 0) {
-        fused_raw_tile_member(smem, reinterpret_cast<const unsigned *>(iq), mid, ctl, rc, xcc, rank, teams, trank, tasks, TEE ? tee : nullptr);
+    if (RAW != 0 && kind == 0) {
+        fused_raw_tile_member<RAW ? RAW : 12>(smem, reinterpret_cast<const unsigned *>(iq), mid, ctl, rc, xcc, rank, teams, trank, tasks, channels, TEE ? tee : nullptr);
         fused_leave(ctl, host_status, xcc, s_ctl);
     } else if (kind == 0) {
         // =============================== tile member ===============================

@@ -19,8 +19,9 @@
 //     engine stores wr_c[i] = wr_c[m - 1 - i] exactly): 78,912 bytes, two workgroups per CU;
 //   * a row wave transforms FOUR rows at a time (16 lanes per row, 128 = 8 x 4 x 4: doppler_row_128), the HH and the
 //     VV row of two gates, so Zdb and Zdr leave with the task that produced them; every wave serves both halves;
-//   * wire-format input (RAW instantiation): the tile members read the 12-byte samples themselves -- ONE
-//     16-byte load per lane and row as in the planar form (fused_b_tile_addr), byte swap + conversion in stage 1.
+//   * wire-format input (RAW instantiations): the tile members read the 12-byte samples -- or the 8-byte ones of
+//     WRP_FLAG_WIRE_8 -- themselves: ONE 16-byte load per lane and row as in the planar form (fused_b_tile_addr), byte swap +
+//     conversion in stage 1.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -60,6 +61,15 @@ __device__ __forceinline__ void rb_derive_twiddles(cf (&tw)[16])
 // 1024 x 512 launch's input: beside a PLAIN stream the rewritten slot does not stay in the L2 (83 % of the intermediate
 // was written back: WRITE_SIZE 1.75 MB per sector, profiles/r03/fused_b_input_policy.log).
 constexpr int FUSED_B_INPUT_AUX = AUX_NT;
+// the row waves touch the slow lines (wrp_fused.h: fused_touch_slow_lines) of the input of the task this many tasks ahead
+// (the tile members request a task's input during the task before it), behind their hand-over of this half; 0 = never
+#ifndef WRP_FUSED_B_TOUCH_AHEAD
+#define WRP_FUSED_B_TOUCH_AHEAD 2
+#endif
+#ifndef WRP_FUSED_B_TOUCH_HALF
+#define WRP_FUSED_B_TOUCH_HALF 0
+#endif
+constexpr int FUSED_B_TOUCH_AHEAD = WRP_FUSED_B_TOUCH_AHEAD, FUSED_B_TOUCH_HALF = WRP_FUSED_B_TOUCH_HALF;
 // Request pacing (wrp_fused.h): 16 = one load at a time over the task, 1.69 us/sector, HBM traffic 1.13 x the algorithmic
 // bytes; 4 = four quarters, 1.74 us/sector, 1.06 x (the smoother stream leaves fewer non-temporal lines per L2 set to evict
 // in place of the slot's): profiles/r03/fused_b_input_policy.log, ab_request_pacing_B.log.
@@ -67,18 +77,21 @@ constexpr int FUSED_B_INPUT_AUX = AUX_NT;
 // sector.cpp:52-62) + 4 ch bytes; the lane's two samples of a row are 24 contiguous bytes of which the 16 from byte 4 ch
 // on hold its channel's dword of the first sample in .x and of the second in .w (.y, .z: the dwords in between, never
 // used) -- ONE 16-byte load per row as in the planar form, the same sixteen requests per task, no decode pass.
-template <bool RAW>
+// RAW = 8 (hhI hhQ vvI vvQ: the feeder has dropped VH): the lane's two samples ARE 16 contiguous bytes, hh0 vv0 hh1 vv1; both
+// channels' members load the same bytes and pick their dword in the byte permute of the conversion (wire_sample2) -- the
+// planar form's geometry (64 bytes of every 1 KiB row per member) with half the bytes from HBM.
+template <int RAW>
 __device__ __forceinline__ void fused_b_tile_addr(const float2 *src, int col_base, bool valid, rsrc_t &rs, int &voff, int &row_stride)
 {
     const int w = wave_id();
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     const int p0 = w * 16 + (l >> 2), cp = l & 3;
-    rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * (RAW ? 12u : 8u) : 0u);
-    voff = (p0 * RB_N + col_base + cp * 2) * (RAW ? 12 : 8);
-    row_stride = RB_N * (RAW ? 12 : 8);
+    rs = make_rsrc(src, valid ? (unsigned)RB_M * RB_N * (RAW ? RAW : 8) : 0u);
+    voff = (p0 * RB_N + col_base + cp * 2) * (RAW ? RAW : 8);
+    row_stride = RB_N * (RAW ? RAW : 8);
 }
-template <int QUARTER, bool RAW = false>
+template <int QUARTER, int RAW = 0>
 __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                   float4 (&v)[16], float2 &wdv, bool valid)
 {
@@ -94,7 +107,7 @@ __device__ __forceinline__ void fused_b_tile_load(const float2 *src /* wave-unif
 }
 
 // ONE row load of the next tile (rows p0 + 128 R): the tile is requested a piece at a time over the task, see wrp_fused.h
-template <int R, bool RAW = false>
+template <int R, int RAW = 0>
 __device__ __forceinline__ void fused_b_tile_load1(const float2 *src /* wave-uniform */, int col_base, const float *wd,
                                                    float4 (&v)[16], float2 &wdv, bool valid)
 {
@@ -121,8 +134,9 @@ __device__ __forceinline__ void fused_b_stage1_tables(const unsigned char *smem,
     rb_derive_twiddles(tw);
 }
 
-template <int COLUMN, bool RAW = false>
-__device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const cf (&tw)[16], cf (&g)[8])
+template <int COLUMN, int RAW = 0>
+__device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4 (&v)[16], float2 wdv, const cf (&tw)[16], cf (&g)[8],
+                                               unsigned wire_sel = 0 /* RAW = 8: WIRE_SEL_HH or WIRE_SEL_VV, wave-uniform */)
 {
     typedef FusedTileB T;
     int tid = threadIdx.x;
@@ -139,7 +153,8 @@ __device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const float wgt = wr[r] * (COLUMN ? wdv.y : wdv.x);
-        if (RAW) a[r] = cscale(wire_sample(COLUMN ? v[r].w : v[r].x), wgt);   // exact conversion: bit-identical to decode_wire + the planar form
+        if (RAW == 12) a[r] = cscale(wire_sample(COLUMN ? v[r].w : v[r].x), wgt);   // exact conversion: bit-identical to decode_wire + the planar form
+        else if (RAW == 8) a[r] = cscale(COLUMN ? wire_sample2(v[r].z, v[r].w, wire_sel) : wire_sample2(v[r].x, v[r].y, wire_sel), wgt);
         else a[r] = COLUMN ? cscale(make_float2(v[r].z, v[r].w), wgt) : cscale(make_float2(v[r].x, v[r].y), wgt);
     }
     fft16<-1>(a);
@@ -242,9 +257,9 @@ __device__ __forceinline__ void fused_b_store(float2 *mid /* wave-uniform */, in
     }
 }
 
-template <int TAPS, bool STAMPS = false, bool TEE = false, bool RAW = false>
+template <int TAPS, bool STAMPS = false, bool TEE = false, int RAW = 0 /* wire-format input: bytes per sample (12 or 8), 0 = planar */>
 __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_chain_2048x128(
-    const float2 *__restrict__ iq,   // [S][C][2048][128]; RAW: the wire format, [S][2048 x 128][12 bytes]
+    const float2 *__restrict__ iq,   // [S][C][2048][128]; RAW: the wire format, [S][2048 x 128][RAW bytes]
     float *__restrict__ out,         // [S][1024][2]
     float2 *pool,                    // [8][FUSED_TEAM_ELEMS]: per team ONE slot [2 channels][512][128] through which both halves go
     FusedCtl *ctl, RangeConsts rc /* wr_c symmetric */, const float2 *__restrict__ tw_n /* exp(+2 pi i k / 128) */, int n_sectors,
@@ -295,12 +310,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
     if (kind == 0) {
         // =============================== tile member: channel rank >> 4, 8-column tile rank & 15 ===============================
         const int ch = rank >> 4;
+        const unsigned wire_sel = __builtin_amdgcn_readfirstlane(ch ? WIRE_SEL_VV : WIRE_SEL_HH);
         // the member's 8-column tile of task q: rotated by TWO from task to task (the pair t, t ^ 1 keeps asking for the two
         // halves of the same lines), so that a tile that loads slowly is a transient of every member instead of one member
         // that is late in every task (wrp_fused.h: tile_col)
         auto tile_col = [&](int q) { return (((rank & 15) + 2 * q) & 15) * 8; };
         auto tile_src = [&](int q) {   // RAW: the sector's samples from byte 4 ch on (float2 units: 12 bytes = 1.5)
-            if (RAW) return reinterpret_cast<const float2 *>(reinterpret_cast<const unsigned char *>(iq) + (size_t)(trank + q * teams) * RB_M * RB_N * 12 + 4 * ch);
+            // 12-byte samples: from byte 4 ch on (the channel's dwords of a lane's two samples are then .x and .w of its 16
+            // bytes); 8-byte samples: the lane's two samples ARE its 16 bytes (hh0 vv0 hh1 vv1), the channel is picked in stage 1
+            if (RAW) return reinterpret_cast<const float2 *>(reinterpret_cast<const unsigned char *>(iq) + (size_t)(trank + q * teams) * RB_M * RB_N * RAW + (RAW == 12 ? 4 * ch : 0));
             return iq + ((size_t)(trank + q * teams) * channels + ch) * RB_M * (size_t)RB_N;
         };
         float4 v[16];
@@ -328,14 +346,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 cf tw[16];
                 stamp(q, 0);
                 fused_b_stage1_tables(smem, tw);
-                fused_b_stage1<0, RAW>(smem, v, wdv, tw, ga);
+                fused_b_stage1<0, RAW>(smem, v, wdv, tw, ga, wire_sel);
                 stamp(q, 5);
                 // half 1 of the previous task was stored half a stage ago: drained and counted here (see wrp_fused.h)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int last = 0;
                 if (l == 0) last = atomicAdd(s_arrived, 1) == 8 * q + 7;
                 if (q > 0 && __builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->stored[1][xcc], l, rank, (unsigned)q);
-                fused_b_stage1<1, RAW>(smem, v, wdv, tw, gc);
+                fused_b_stage1<1, RAW>(smem, v, wdv, tw, gc, wire_sel);
             }
             __syncthreads();                    // A1: group 0 is in the image
             stamp(q, 1);
@@ -395,6 +413,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
         const rsrc_t rs = make_rsrc(mid, (unsigned)FUSED_TEAM_ELEMS * 8u);
         const int Q = 8 * rank + w;
         const int voff = (chn * 256 + Q) * 2048 + (i >> 3) * 128 + pb * 64 + (i & 7) * 8;   // element j = i + 16 r: tile 2 r + (i >> 3)
+        // the slow lines of the sectors to come (wrp_fused.h: fused_touch_slow_lines): the bytes of task q that the tile
+        // members read -- planes HH and VV of the planar block, or the sector's wire bytes
+        const unsigned touch_bytes = RAW ? (unsigned)RB_M * RB_N * RAW : 2u * RB_M * RB_N * 8u;
+        auto touch = [&](int q) {
+            const unsigned char *p = reinterpret_cast<const unsigned char *>(iq) +
+                (size_t)(trank + (q >= 0 && q < tasks ? q : 0) * teams) * (RAW ? (size_t)RB_M * RB_N * RAW : (size_t)channels * RB_M * RB_N * 8);
+            return fused_touch_slow_lines(p, touch_bytes, 8 * rank + w, l, FUSED_B_TOUCH_AHEAD > 0 && q >= 0 && q < tasks);
+        };
+        float touched = touch(FUSED_B_TOUCH_AHEAD - 1);      // (task 0's tile is on its way already)
 #pragma unroll 1
         for (int q = 0; q < tasks; q++) {
             bool there = true;
@@ -417,6 +444,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
                 if (__builtin_amdgcn_readfirstlane(last)) l2_flag32(ctl->loaded[g][xcc], l, rank, (unsigned)(q + 1));
                 __builtin_amdgcn_s_setprio(0);
                 stamp(q, 4 * g + 2);
+                if (FUSED_B_TOUCH_AHEAD > 0 && g == FUSED_B_TOUCH_HALF) {
+                    // behind the wave's part of the hand-over chain, a transform and a wait in front of its next row loads
+                    // (which return in order behind this one); the previous touch has long landed
+                    asm volatile("" :: "v"(touched));
+                    touched = touch(q + FUSED_B_TOUCH_AHEAD);
+                }
                 const int gate = fused_b_gate(g, Q, pb);
                 const float S = doppler_row_128<TAPS>(x, rbuf, s_twn, taps, i);
                 const float other = __shfl(S, (l + 32) & 63);     // the VV row sum sits 32 lanes above the HH one
@@ -425,6 +458,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             }
             if (!there) break;
         }
+        asm volatile("" :: "v"(touched));
         flush_stamps();
         fused_leave(ctl, host_status, xcc, s_ctl);
     }

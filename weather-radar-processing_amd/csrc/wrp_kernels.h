@@ -639,19 +639,24 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 // read_matrix builds on the CPU (rpv2.cu:369-383).  One sample per thread: one 12-byte load,
 // `channels` coalesced 8-byte stores.  Integer -> float is exact, so this is bit-identical to
 // Sector::fromByteArray + the scatter loop.
+// WB = 8: the same sample without its VH pair (hhI hhQ vvI vvQ), which the feeder drops in the copy it makes anyway
+// (WRP_FLAG_WIRE_8, include/wrp.h): no output reads VH (rpv2.cu:199-213); a third plane of the block is left as it is.
 // =============================================================================================
-__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [sectors = gridDim.y][count][3] dwords
+template <int WB>
+__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [sectors = gridDim.y][count][WB / 4] dwords
                                                     float2 *__restrict__ iq,            // [sectors][channels][count]
                                                     int count, int channels, const unsigned *gate)
 {
+    constexpr int D = WB / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count || gate_closed(gate)) return;
-    raw += (size_t)blockIdx.y * count * 3;
+    raw += (size_t)blockIdx.y * count * D;
     iq += (size_t)blockIdx.y * channels * count;
-    const unsigned w0 = raw[3 * t], w1 = raw[3 * t + 1], w2 = raw[3 * t + 2];
-    const unsigned w[3] = {__builtin_bswap32(w0), __builtin_bswap32(w1), __builtin_bswap32(w2)};
+    unsigned w[D];
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < D; c++) w[c] = __builtin_bswap32(raw[D * t + c]);
+#pragma unroll
+    for (int c = 0; c < D; c++)
         if (c < channels)
             iq[(size_t)c * count + t] = make_float2((float)(short)(w[c] >> 16), (float)(short)(w[c] & 0xffffu));
 }

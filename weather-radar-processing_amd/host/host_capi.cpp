@@ -13,6 +13,7 @@
 #include "framing.h"
 #include "sector.h"
 #include "tcp.h"
+#include "wire.h"
 
 extern "C" {
 
@@ -39,6 +40,14 @@ void wrph_sector_read(const char *bytes, size_t nbytes, int sweeps, int samples,
     memcpy(hh, s.hh, cnt);
     memcpy(vv, s.vv, cnt);
     memcpy(vh, s.vh, cnt);
+}
+// WRP_FLAG_WIRE_8's feeder side: 12-byte samples -> 8-byte samples (VH dropped); threads > 1: through a FillPool; portable != 0: the plain loop
+void wrph_wire_drop_vh(unsigned char *dst8, const unsigned char *src12, size_t samples, int threads, int portable)
+{
+    if (portable) { wire_drop_vh_portable(dst8, src12, samples); return; }
+    if (threads <= 1) { wire_drop_vh(dst8, src12, samples); return; }
+    FillPool pool(threads);
+    for (int rep = 0; rep < 3; rep++) pool.drop_vh((char *)dst8, (const char *)src12, samples);     // (the pool is reused per sector)
 }
 void wrph_aftoab(float *af, size_t n, unsigned char *ab) { aftoab(af, n, ab); }
 void wrph_abtoaf(unsigned char *ab, size_t n, float *af) { abtoaf(ab, n, af); }

@@ -22,6 +22,17 @@ RadarProcessor::~RadarProcessor()
     if (eng_) wrp_destroy(eng_);
 }
 
+RadarProcessor::Source RadarProcessor::drop_vh_source(Source src12)
+{
+    return [this, src12](char *buf, size_t bytes) {
+        const size_t samples = bytes / WIRE8_BYTES_PER_SAMPLE;
+        stage_.resize(samples * WIRE_BYTES_PER_SAMPLE);
+        if (!src12(stage_.data(), stage_.size())) return false;
+        wire_drop_vh((unsigned char *)buf, (const unsigned char *)stage_.data(), samples);
+        return true;
+    };
+}
+
 const char *RadarProcessor::last_error() const
 {
     return status_ ? wrp_strerror(status_) : "";
@@ -38,6 +49,15 @@ void RadarProcessor::set_comms(int in_port, int *out_ports, int n_out)
     source_ = [this](char *buf, size_t bytes) {
         // one datagram per range row: m datagrams of 12*n bytes (read_single.cc:145-148)
         const size_t row = (size_t)NUM_BYTES_PER_SAMPLE * n_samples;
+        if (wire_bytes_ == 8) {     // the row lands in a 6 KiB buffer and goes into the slot without its VH samples
+            stage_.resize(row);
+            const size_t row8 = (size_t)WIRE8_BYTES_PER_SAMPLE * n_samples;
+            for (size_t off = 0; off < bytes; off += row8) {
+                if (server_->recv(stage_.data(), row) != (int)row) return false;
+                wire_drop_vh((unsigned char *)buf + off, (const unsigned char *)stage_.data(), n_samples);
+            }
+            return true;
+        }
         for (size_t off = 0; off < bytes; off += row)
             if (server_->recv(buf + off, row) != (int)row) return false;
         return true;
@@ -82,6 +102,7 @@ void RadarProcessor::initialize_streams()
     cfg.ma_count = ma_count;
     cfg.k_range_resolution = (float)k_range_resolution;
     cfg.k_calibration = k_calibration;
+    if (wire_bytes_ == 8) cfg.flags |= WRP_FLAG_WIRE_8;
     status_ = wrp_create(&cfg, device_, &eng_);
 }
 

@@ -7,7 +7,9 @@
 //     radar_processor.cu:239-247);
 //   * copy_result_to_host + send_results wait for the slot's event instead of reading the result
 //     buffer unsynchronised (gpu_1fp_streamcasc.cu:695-697);
-//   * start() returns when the source ends or max_sectors is reached (the reference never returns).
+//   * start() returns when the source ends or max_sectors is reached (the reference never returns);
+//   * set_wire_bytes(8): the sector crosses PCIe WITHOUT its VH samples (WRP_FLAG_WIRE_8: no output reads them,
+//     rpv2.cu:199-213): the copy that brings the bytes into the pinned slot drops them (wire.h).
 #ifndef WRP_HOST_RADAR_PROCESSOR_H
 #define WRP_HOST_RADAR_PROCESSOR_H
 #include <stddef.h>
@@ -21,6 +23,7 @@
 #include <vector>
 
 #include "udpbroadcast.h"
+#include "wire.h"
 #include "wrp.h"
 
 #define NUM_BYTES_PER_SAMPLE (3 * 2 * 2)
@@ -48,11 +51,18 @@ class RadarProcessor {
     void set_unicast(const char *ipv4) { unicast_ = ipv4 ? ipv4 : ""; }   // products to this host instead of the broadcast address
 
     // hooks the reference does not have (tests, file replay, other transports)
-    typedef std::function<bool(char *buf, size_t bytes)> Source;   // one sector of wire bytes; false = end
+    // one sector of wire bytes IN THE PROCESSOR'S FORMAT (wire_bytes() per sample) into buf; false = end.  A source that
+    // delivers the 12-byte samples of sector.cpp:52-62 is wrapped with drop_vh_source() when the format is 8.
+    typedef std::function<bool(char *buf, size_t bytes)> Source;
     typedef std::function<void(int which, int sector, int elevation, const unsigned char *frame, size_t bytes)> Sink;
     void set_source(Source s) { source_ = std::move(s); }
     void set_sink(Sink s) { sink_ = std::move(s); }
     void set_device(int d) { device_ = d; }
+    void set_wire_bytes(int b) { wire_bytes_ = b == 8 ? 8 : 12; }   // before start() / set_comms()
+    int wire_bytes() const { return wire_bytes_; }
+    // a source of 12-byte samples as a source of 8-byte ones: the sector goes through a staging buffer of this processor,
+    // the copy into `buf` drops VH
+    Source drop_vh_source(Source src12);
     // this processor owns the sectors s with s % world == rank of every elevation (world GPUs, one
     // processor each); the processors of one scan share `turn`
     void set_shard(int rank, int world, SectorTurnstile *turn) { shard_rank_ = rank; shard_world_ = world; turn_ = turn; }
@@ -83,6 +93,8 @@ class RadarProcessor {
     double seconds_ = 0;
     bool with_elevation_ = true;
     int status_ = 0;
+    int wire_bytes_ = 12;
+    std::vector<char> stage_;     // drop_vh_source / the UDP rows: 12-byte samples on their way into an 8-byte slot
     std::string unicast_;
     Source source_;
     std::function<void()> on_ready_;

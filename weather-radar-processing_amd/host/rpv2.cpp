@@ -1,7 +1,7 @@
 // rpv2.cpp -- entry point with the reference's name (Makefile:4 builds `rpv2`; main.cpp:3-16 is
 // the class-based variant).  usage:
 //   rpv2 [num_streams] [--in udp:PORT | file:PATH | synthetic | synthetic:copy[:T]] [--bind-numa] [--out udp:PORT_ZDB,PORT_ZDR[@IPV4] | file:PATH | none]
-//        [--sectors N] [--device D | --devices D0,D1,...] [--no-elevation] [--scan SECTORS,ELEVATIONS]
+//        [--sectors N] [--device D | --devices D0,D1,...] [--no-elevation] [--scan SECTORS,ELEVATIONS] [--wire8]
 // Defaults reproduce main.cpp:10-15: 143 sectors x 9 elevations of 1024 x 512, UDP 19001 in,
 // 19002 / 19003 out (broadcast, as the reference; @IPV4 sends the products to one host instead).  file: input is a concatenation of wire-format sectors (12 bytes/sample),
 // file: output a concatenation of frames, Zdb then Zdr per sector.  Frame header: [sector BE16] for udp: products
@@ -21,6 +21,10 @@
 // T = 1): the end-to-end rate WITH the host's share of the work.  Each GPU thread has a source of its own
 // (no turnstile), and --sectors counts per GPU.
 // --bind-numa: every GPU thread (and its helpers) runs on the CPUs of the NUMA node its GPU hangs on.
+// --wire8: the sectors cross PCIe without their VH samples (WRP_FLAG_WIRE_8: 8 bytes per sample instead of 12; no output
+// reads VH, rpv2.cu:199-213): the copy that brings a sector into its pinned slot -- from the socket's row buffer, the
+// file's staging buffer or synthetic:copy's pageable buffer -- drops bytes 8..11 of every sample (host/wire.h).  The
+// input (socket, file) is the reference's 12-byte format either way.
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,59 +43,9 @@
 #include <mutex>
 
 #include "radar_processor.h"
+#include "wire.h"
 
 namespace {
-
-// memcpy of one sector split over T threads (the caller is one of them); the helpers live as long as the pool
-class FillPool {
-  public:
-    explicit FillPool(int threads) : n_(threads < 1 ? 1 : threads)
-    {
-        for (int t = 1; t < n_; t++) workers_.emplace_back([this, t] { run(t); });
-    }
-    ~FillPool()
-    {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
-        cv_.notify_all();
-        for (auto &w : workers_) w.join();
-    }
-    void copy(char *dst, const char *src, size_t bytes)
-    {
-        if (n_ == 1) { memcpy(dst, src, bytes); return; }
-        { std::lock_guard<std::mutex> lk(mu_); dst_ = dst; src_ = src; bytes_ = bytes; left_ = n_ - 1; gen_++; }
-        cv_.notify_all();
-        part(0);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return left_ == 0; });
-    }
-
-  private:
-    void part(int t)
-    {
-        const size_t chunk = ((bytes_ + n_ - 1) / n_ + 4095) & ~(size_t)4095, lo = (size_t)t * chunk;
-        if (lo < bytes_) memcpy(dst_ + lo, src_ + lo, lo + chunk <= bytes_ ? chunk : bytes_ - lo);
-    }
-    void run(int t)
-    {
-        long seen = 0;
-        for (;;) {
-            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
-            part(t);
-            { std::lock_guard<std::mutex> lk(mu_); left_--; }
-            done_.notify_one();
-        }
-    }
-    const int n_;
-    std::vector<std::thread> workers_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    long gen_ = 0;
-    int left_ = 0;
-    bool stop_ = false;
-    char *dst_ = nullptr;
-    const char *src_ = nullptr;
-    size_t bytes_ = 0;
-};
 
 // the calling thread (and every thread it starts later) onto the CPUs of the GPU's NUMA node; false = left alone
 bool bind_to_gpu_numa(int device)
@@ -125,7 +79,7 @@ int main(int argc, char **argv)
 {
     int num_streams = 2;
     long sectors = -1;
-    bool with_elev = true, with_elev_set = false, bind_numa = false;
+    bool with_elev = true, with_elev_set = false, bind_numa = false, wire8 = false;
     int scan_sectors = 143, scan_elevations = 9;
     std::vector<int> devices{0};
     std::string in = "udp:19001", out = "udp:19002,19003";
@@ -146,6 +100,7 @@ int main(int argc, char **argv)
             }
         } else if (a == "--no-elevation") { with_elev = false; with_elev_set = true; }
         else if (a == "--bind-numa") bind_numa = true;
+        else if (a == "--wire8") wire8 = true;
         else if (a[0] != '-') { num_streams = atoi(a.c_str()); if (num_streams < 1) num_streams = 1; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -155,6 +110,7 @@ int main(int argc, char **argv)
     for (int g = 0; g < G; g++) {
         procs.emplace_back(new RadarProcessor(scan_sectors, 1024, 512, scan_elevations, num_streams));
         procs[g]->set_device(devices[g]);
+        procs[g]->set_wire_bytes(wire8 ? 8 : 12);
         procs[g]->set_max_sectors(sectors);
         if (G > 1) procs[g]->set_shard(g, G, in.rfind("synthetic", 0) == 0 ? nullptr : &turn);   // synthetic: a source per GPU
     }
@@ -214,7 +170,8 @@ int main(int argc, char **argv)
                 sink = [cl](int which, int, int, const unsigned char *f, size_t n) { (*cl)[which]->send((const char *)f, n); };
             } else if (out != "none") { fprintf(stderr, "unknown --out %s\n", out.c_str()); return 2; }
             for (auto &p : procs) {
-                p->set_source(src);
+                // file: and udp: deliver the reference's 12-byte samples; synthetic sources fill whatever the slot holds
+                p->set_source(wire8 && in.rfind("synthetic", 0) != 0 ? p->drop_vh_source(src) : src);
                 if (sink) p->set_sink(sink);
             }
         }
@@ -236,7 +193,10 @@ int main(int argc, char **argv)
         pools[g].reset(new FillPool(fill_threads));
         FillPool *pool = pools[g].get();
         const char *from = pageable[g].data();
-        procs[g]->set_source([pool, from, bytes](char *buf, size_t n) { pool->copy(buf, from, n < bytes ? n : bytes); return true; });
+        if (wire8)   // n = 8 bytes per sample of the slot; the pageable buffer holds the 12-byte samples
+            procs[g]->set_source([pool, from](char *buf, size_t n) { pool->drop_vh(buf, from, n / WIRE8_BYTES_PER_SAMPLE); return true; });
+        else
+            procs[g]->set_source([pool, from, bytes](char *buf, size_t n) { pool->copy(buf, from, n < bytes ? n : bytes); return true; });
     };
     const auto t0 = std::chrono::steady_clock::now();
     if (G == 1) {
@@ -271,7 +231,7 @@ int main(int argc, char **argv)
     pools.clear();
     if (!rc) fprintf(stderr, "rpv2: %ld sectors processed in %.3f s (%.0f sectors/s end to end, %d GPU thread%s, %d slots each%s%s)\n", total,
                      dt, total / dt, G, G > 1 ? "s" : "", num_streams,
-                     copy_source ? (std::string(", host fill by ") + std::to_string(fill_threads) + " thread(s) per GPU").c_str() : "",
+                     copy_source ? (std::string(", host fill by ") + std::to_string(fill_threads) + " thread(s) per GPU" + (wire8 ? ", VH dropped (8 bytes per sample)" : "")).c_str() : "",
                      bind_numa ? (bound[0] ? ", NUMA-bound" : ", NUMA binding not possible") : "");
     return rc;
 }
