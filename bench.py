@@ -36,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 SETTLE_S = 0.3     # untimed launches before the W warm-up steps: the clocks reach their working point (see settle())
 
 
@@ -237,6 +237,62 @@ def main():
     def step():
         eng.process_batch_device(d_iq.data_ptr(), S, d_out.data_ptr())
 
+    def profile_json(name):
+        """profiles/rNN/<name> when it was measured on the library sources that run here (fingerprint), else (None, why)."""
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, name)))
+        except Exception:
+            return None, "no profiles/%s/%s for this build" % (PROFILE_ROUND, name)
+        if tj.get("fingerprint") != wrp_amd.source_fingerprint():
+            return None, "profiles/%s/%s was measured on other sources (fingerprint differs)" % (PROFILE_ROUND, name)
+        return tj, tj.get("source", "")
+
+    def traffic_of(name, per_launch, fused_launch=True):
+        tj, note = profile_json(name)
+        if tj is None:
+            return None, note
+        if tj.get("sectors_per_launch") != per_launch or tj.get("fused") != fused_launch:
+            return None, "profiles/%s/%s was measured on another configuration" % (PROFILE_ROUND, name)
+        return round(tj["bytes_per_launch"]), note
+
+    def wire_pool(sectors, wb):
+        """sectors [K][2][m][n] complex (integer valued) -> [K][m*n*wb] bytes: hhI hhQ vvI vvQ (vhI vhQ), big-endian int16"""
+        k, _, mm, nn = sectors.shape
+        w = np.zeros((k, mm * nn, wb // 2), dtype=">i2")
+        for c in range(2):
+            w[:, :, 2 * c] = sectors[:, c].real.reshape(k, -1)
+            w[:, :, 2 * c + 1] = sectors[:, c].imag.reshape(k, -1)
+        return np.frombuffer(w.tobytes(), np.uint8).reshape(k, -1)
+
+    def raw_sweep(e, sectors, wb, d_ref, traffic_name, what):
+        """the sweep in a wire format through e's raw batch entry: untimed settle, wall clock over <= 100 launches"""
+        mm, nn = sectors.shape[2:]
+        d_wp = torch.from_numpy(wire_pool(sectors, wb)).to(dev)
+        d_raw = d_wp[torch.arange(S, device=dev) % len(sectors)].contiguous()      # [S][m*n*wb] bytes, distinct blocks
+        d_o = torch.empty_like(d_ref)
+        del d_wp
+        t_end = time.perf_counter() + max(args.settle, 0.05)     # the GPU has idled through the host's conversion above
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                e.process_batch_raw_device(d_raw.data_ptr(), S, d_o.data_ptr())
+            e.check()
+        steps = max(10, min(args.steps, 100))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.process_batch_raw_device(d_raw.data_ptr(), S, d_o.data_ptr())
+        e.check()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        algo_w = mm * nn * wb + (mm // 2) * 8
+        tr, note = traffic_of(traffic_name, S)
+        r = {"value": round(world * S * steps / dt, 1), "unit": "sectors/s", "steps": steps, "bytes_per_sample": wb,
+             "algorithmic_bytes_per_sector": algo_w, "achieved": round(algo_w * S * steps / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
+             "frac": round(algo_w * S * steps / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_note": note,
+             "bit_identical_to_planar": bool(torch.equal(d_o, d_ref)), "fused_fallbacks": e.fused_fallbacks, "what": what}
+        del d_raw, d_o
+        return r
+
     def barrier():
         torch.cuda.synchronize()
         if ctl is not None:
@@ -297,25 +353,20 @@ def main():
     # HBM traffic per launch from the rocprofv3 PMC run of the SAME library sources (FETCH_SIZE / WRITE_SIZE in
     # separate passes, gfx950 correction applied; tools/profile_pmc.sh -> tools/make_traffic.py).  The file
     # records a fingerprint of csrc/, include/ and the compiler flags: anything else reads null.
-    traffic, traffic_note = None, "no traffic file for this build"
-    try:
-        tname = "traffic.json" if args.shape == "A" else "traffic_%s.json" % args.shape
-        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, tname)))
-        if tj.get("fingerprint") != wrp_amd.source_fingerprint():
-            traffic_note = "profiles/%s/%s was measured on other sources (fingerprint differs)" % (PROFILE_ROUND, tname)
-        elif tj.get("sectors_per_launch") != per_launch or tj.get("fused") != fused:
-            traffic_note = "profiles/%s/%s was measured on another configuration" % (PROFILE_ROUND, tname)
-        else:
-            traffic = round(tj["bytes_per_launch"])
-            traffic_note = tj.get("source", "")
-    except Exception:
-        pass
+    traffic, traffic_note = traffic_of("traffic.json" if args.shape == "A" else "traffic_%s.json" % args.shape, per_launch, fused)
+    # what the launch keeps busy besides HBM: from the PMC passes of the same sources (tools/make_busy.py) --
+    # valu_busy = SQ_INSTS_VALU x 2 cycles / (SIMDs x kernel cycles), lds_busy = SQ_LDS_IDX_ACTIVE / (CUs x kernel cycles) --
+    # and the launch with every request of its input dropped by the descriptor (a timing build: tools/make_floor.sh)
+    busy, _ = profile_json("busy.json" if args.shape == "A" else "busy_%s.json" % args.shape)
+    floor, _ = profile_json("floor.json" if args.shape == "A" else "floor_%s.json" % args.shape)
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
         "kernel": kernel, "algorithmic_bytes_per_sector": algo, "sectors_per_launch": per_launch,
         "algorithmic_bytes_per_launch": algo * per_launch,
         "avg_launch_us": round(ms_total * 1e3 / (iters * launches), 2),
+        "valu_busy": busy and busy.get("valu_busy"), "lds_busy": busy and busy.get("lds_busy"),
+        "no_input_us_per_sector": floor and floor.get("no_input_us_per_sector"),
     }
     if not fused:
         roofline["range_pass_us_per_sector"] = round(ms_range * 1e3 / (iters * S), 3)
@@ -343,40 +394,21 @@ def main():
     # The same sweep in the WIRE format, device-resident: the tile workgroups of the fused launch read the
     # 12-byte samples themselves.  A roofline entry of its own -- the headline stays on the fp32 definition of SURVEY 8d.
     wire = None
-    if args.shape == "A" and (not args.no_extras or os.environ.get("WRP_BENCH_WIRE")):
-        wsec = []
-        for k in range(8):
-            w = np.zeros((m * n, 6), dtype=">i2")
-            for c in range(2):
-                w[:, 2 * c] = pool[k][c].real.ravel()
-                w[:, 2 * c + 1] = pool[k][c].imag.ravel()
-            wsec.append(np.frombuffer(w.tobytes(), np.uint8))
-        d_wpool = torch.from_numpy(np.stack(wsec)).to(dev)
-        d_raw = d_wpool[torch.arange(S, device=dev) % 8].contiguous()          # [S][m*n*12] bytes: 2.2 GiB, distinct blocks
-        d_out_w = torch.empty_like(d_out)
-        del d_wpool
-        for _ in range(max(args.warmup, 10)):
-            eng.process_batch_raw_device(d_raw.data_ptr(), S, d_out_w.data_ptr())
-        eng.check()
-        t_end = time.perf_counter() + args.settle      # the GPU has idled through the host's conversion above: back to the
-        while time.perf_counter() < t_end:              # working point first, as for the headline and for shape_b
-            for _ in range(8):
-                eng.process_batch_raw_device(d_raw.data_ptr(), S, d_out_w.data_ptr())
-            eng.check()
-        wsteps = max(10, min(args.steps, 100))
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(wsteps):
-            eng.process_batch_raw_device(d_raw.data_ptr(), S, d_out_w.data_ptr())
-        eng.check()
-        barrier()
-        wdt = max_over_ranks(time.perf_counter() - t0)
-        walgo = m * n * 12 + (m // 2) * 8
-        wire = {"value": round(world * S * wsteps / wdt, 1), "unit": "sectors/s", "steps": wsteps,
-                "algorithmic_bytes_per_sector": walgo, "achieved": round(walgo * S * wsteps / wdt / 1e9, 1), "peak": HBM_PEAK_GBS,
-                "frac": round(walgo * S * wsteps / wdt / 1e9 / HBM_PEAK_GBS, 4), "bit_identical_to_planar": bool(torch.equal(d_out_w, d_out)),
-                "what": "wrp_process_batch_raw_device: 12 B/sample big-endian int16 read by the tile workgroups (6 MiB/sector), wall clock"}
-        del d_raw, d_out_w
+    if not args.no_extras or os.environ.get("WRP_BENCH_WIRE"):
+        want_wb = int(os.environ.get("WRP_BENCH_WIRE", "0") or 0)       # profiling passes: 12 or 8 only
+        tag = "" if args.shape == "A" else args.shape
+        mib = m * n / 2**20
+        if want_wb in (0, 1, 12):
+            wire = raw_sweep(eng, pool, 12, d_out, "traffic_%sW.json" % tag,
+                             "wrp_process_batch_raw_device: 12 B/sample big-endian int16 read by the tile workgroups (%g MiB/sector), wall clock" % (12 * mib))
+        if want_wb in (0, 8):
+            with wrp_amd.Engine(device=dev_index, n_slots=1, n_sectors=1, n_elevations=1, m=m, n=n, flags=wrp_amd.FLAG_WIRE_8) as e8:
+                w8 = raw_sweep(e8, pool, 8, d_out, "traffic_%sW8.json" % tag,
+                               "WRP_FLAG_WIRE_8: 8 B/sample (hh, vv; VH dropped by the feeder) read by the tile workgroups (%g MiB/sector), wall clock" % (8 * mib))
+            if wire is None:
+                wire = w8
+            else:
+                wire["wire8"] = w8
 
     # BASELINE configs[4] (2048 range gates x 128 pulses) through its own fused launch, on this GPU, in the default line: a
     # second engine, its own sweep (360 x 4 MiB, distinct blocks), wall clock + HIP events + spot check against the oracle.
@@ -416,17 +448,7 @@ def main():
             b_ms = eb.time_batch_device(d_iq_b.data_ptr(), S, d_out_b.data_ptr(), b_iters)[0]
             balgo = eb.algorithmic_bytes
             b_ach = balgo * S * b_iters / (b_ms * 1e-3) / 1e9
-            b_traffic, b_note = None, "no traffic file for this build"
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_B.json")))
-                if tj.get("fingerprint") != wrp_amd.source_fingerprint():
-                    b_note = "profiles/%s/traffic_B.json was measured on other sources (fingerprint differs)" % PROFILE_ROUND
-                elif tj.get("sectors_per_launch") != S or not tj.get("fused"):
-                    b_note = "profiles/%s/traffic_B.json was measured on another configuration" % PROFILE_ROUND
-                else:
-                    b_traffic, b_note = round(tj["bytes_per_launch"]), tj.get("source", "")
-            except Exception:
-                pass
+            b_traffic, b_note = traffic_of("traffic_B.json", S)
             shape_b = {"value": round(world * S * bsteps / bdt, 1), "unit": "sectors/s", "steps": bsteps,
                        "workload": f"BASELINE configs[4]: C=2, m=2048 range gates, n=128 pulses, fp32 complex, {S} sectors per launch, device-resident",
                        "kernel": "fused_chain_2048x128", "fused_fallbacks": eb.fused_fallbacks,
@@ -436,89 +458,104 @@ def main():
                        "frac_wall_clock": round(balgo * S * bsteps / bdt / 1e9 / HBM_PEAK_GBS, 4), "spot_check_vs_oracle": b_ok,
                        "what": "`value`: wall clock over `steps` launches; `achieved` / `frac`: HIP events on the engine's stream over "
                                "%d launches, as the headline's roofline" % b_iters}
-            # ... and the same sweep in the wire format, read by that launch's tile workgroups (3 MiB per sector instead of 4)
-            wb = np.zeros((8, mb * nb, 6), dtype=">i2")
-            for k in range(8):
-                for c in range(2):
-                    wb[k, :, 2 * c] = pool_b[k][c].real.ravel()
-                    wb[k, :, 2 * c + 1] = pool_b[k][c].imag.ravel()
-            d_wb = torch.from_numpy(np.frombuffer(wb.tobytes(), np.uint8).reshape(8, -1)).to(dev)
-            d_raw_b = d_wb[torch.arange(S, device=dev) % 8].contiguous()
-            d_out_bw = torch.empty_like(d_out_b)
-            del d_wb
-            t_end = time.perf_counter() + args.settle
-            while time.perf_counter() < t_end:
-                for _ in range(8):
-                    eb.process_batch_raw_device(d_raw_b.data_ptr(), S, d_out_bw.data_ptr())
-                eb.check()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(bsteps):
-                eb.process_batch_raw_device(d_raw_b.data_ptr(), S, d_out_bw.data_ptr())
-            eb.check()
-            barrier()
-            bwdt = max_over_ranks(time.perf_counter() - t0)
-            bwalgo = mb * nb * 12 + (mb // 2) * 8
-            shape_b["wire_format_input"] = {
-                "value": round(world * S * bsteps / bwdt, 1), "unit": "sectors/s", "steps": bsteps, "algorithmic_bytes_per_sector": bwalgo,
-                "achieved": round(bwalgo * S * bsteps / bwdt / 1e9, 1), "peak": HBM_PEAK_GBS,
-                "frac": round(bwalgo * S * bsteps / bwdt / 1e9 / HBM_PEAK_GBS, 4), "bit_identical_to_planar": bool(torch.equal(d_out_bw, d_out_b)),
-                "fused_fallbacks": eb.fused_fallbacks,
-                "what": "wrp_process_batch_raw_device on the 2048 x 128 engine: 12 B/sample read by the tile workgroups (3 MiB/sector), wall clock"}
-            del d_iq_b, d_out_b, d_raw_b, d_out_bw
+            # ... and the same sweep in the wire formats, read by that launch's tile workgroups (3 / 2 MiB per sector instead of 4)
+            shape_b["wire_format_input"] = raw_sweep(eb, pool_b, 12, d_out_b, "traffic_BW.json",
+                "wrp_process_batch_raw_device on the 2048 x 128 engine: 12 B/sample read by the tile workgroups (3 MiB/sector), wall clock")
+            with wrp_amd.Engine(device=dev_index, n_slots=1, n_sectors=1, n_elevations=1, m=mb, n=nb, flags=wrp_amd.FLAG_WIRE_8) as eb8:
+                shape_b["wire_format_input"]["wire8"] = raw_sweep(eb8, pool_b, 8, d_out_b, "traffic_BW8.json",
+                    "WRP_FLAG_WIRE_8 on the 2048 x 128 engine: 8 B/sample (2 MiB/sector: a member's bytes are the planar form's, both channels' members read the same), wall clock")
+            del d_iq_b, d_out_b
 
     # end to end: every sector crosses PCIe.  Wire-format sector (12 B/sample, big-endian int16, 6 MiB) in
     # the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB, 4 slots cascading, all ranks at once.
     end_to_end = None
     if not args.no_end_to_end:
-        w = np.zeros((m * n, 6), dtype=">i2")      # (rows of 12 n bytes: the wire format is shape-agnostic)
-        for c in range(2):
-            w[:, 2 * c] = pool[0][c].real.ravel()
-            w[:, 2 * c + 1] = pool[0][c].imag.ravel()
-        raw = np.frombuffer(w.tobytes(), np.uint8)
-        for s in range(SLOTS):
-            eng.raw_slot_array(s)[:] = raw
-        dt = 0.0
-        for rep in range(2):                  # the second repetition is the one reported
-            barrier()
-            t0 = time.perf_counter()
-            for k in range(S):
-                s = k % SLOTS
-                if k >= SLOTS:
-                    eng.wait(s)
-                eng.submit_raw(s, k, 0)
-            for s in range(min(SLOTS, S)):
-                eng.wait(s)
-            barrier()
-            dt = max_over_ranks(time.perf_counter() - t0)
         want = O.sector(pool[0][0], pool[0][1], dtype=np.float64)
-        e_ok = bool(np.max(np.abs(eng.result(S - 1, 0)[1:] - want[1:])) < 1e-3)
-        # the same WITH the host's share: the C++ feeder (host/rpv2, one thread per GPU as rpv2.cu:665-683) copies every
-        # sector from a pageable buffer into its pinned slot before it submits it (6 MiB memcpy, as a socket delivers
-        # it), bound to the GPU's NUMA node; once with the feeder thread alone and once with 4 threads sharing the copy
-        with_fill = None
         rpv2 = os.path.join(ROOT, "weather-radar-processing_amd", "host", "rpv2")
-        if args.shape == "A" and os.path.exists(rpv2):
+
+        def cascade(e, wb):
+            """the sweep through e's 4-slot cascade from pinned wire-format slots; the second repetition is the one reported"""
+            raw = wire_pool(pool[:1], wb)[0]
+            for s_ in range(SLOTS):
+                e.raw_slot_array(s_)[:] = raw
+            dt = 0.0
+            for rep in range(2):
+                barrier()
+                t0 = time.perf_counter()
+                for k in range(S):
+                    s_ = k % SLOTS
+                    if k >= SLOTS:
+                        e.wait(s_)
+                    e.submit_raw(s_, k, 0)
+                for s_ in range(min(SLOTS, S)):
+                    e.wait(s_)
+                barrier()
+                dt = max_over_ranks(time.perf_counter() - t0)
+            ok_ = bool(np.max(np.abs(e.result(S - 1, 0)[1:] - want[1:])) < 1e-3)
+            return {"value": round(world * S / dt, 1), "unit": "sectors/s", "bytes_per_sample": wb,
+                    "h2d_GBps_per_gpu": round(S * m * n * wb / dt / 1e9, 1), "spot_check_vs_oracle": ok_}
+
+        def host_fill(wb):
+            """the same WITH the host's share: the C++ feeder (host/rpv2, one thread per GPU as rpv2.cu:665-683) brings every
+            sector from a pageable buffer of 12-byte samples into its pinned slot before it submits it -- a memcpy, or (wire8)
+            the copy that drops VH -- bound to the GPU's NUMA node, with 1 and with 4 threads sharing the copy"""
             import re
-            with_fill = {"unit": "sectors/s", "what": "rpv2 %d --device D --in synthetic:copy:T --bind-numa --out none: pageable -> pinned "
-                         "memcpy by T host thread(s) + H2D + decode + kernels + D2H per sector, all ranks at once" % SLOTS}
+            if args.shape != "A" or not os.path.exists(rpv2):
+                return None
+            r = {"unit": "sectors/s"}
             for T in (1, 4):
                 barrier()
                 out = subprocess.run([rpv2, str(SLOTS), "--device", str(dev_index), "--in", "synthetic:copy:%d" % T, "--bind-numa",
-                                      "--out", "none", "--scan", "%d,1" % S, "--sectors", str(3 * S)], capture_output=True, text=True, timeout=300)
-                mm = re.search(r"\(([0-9.]+) sectors/s end to end", out.stderr)
-                rate = float(mm.group(1)) if mm else 0.0
+                                      "--out", "none", "--scan", "%d,1" % S, "--sectors", str(3 * S)] + (["--wire8"] if wb == 8 else []),
+                                     capture_output=True, text=True, timeout=300)
+                mm_ = re.search(r"\(([0-9.]+) sectors/s end to end", out.stderr)
+                rate = float(mm_.group(1)) if mm_ else 0.0
                 slowest = max_over_ranks(1.0 / rate if rate > 0 else float("inf"))          # every rank takes part
-                rate = world / slowest                                                       # the slowest rank's rate x ranks
-                with_fill["fill_threads_%d" % T] = round(rate, 1)
-                with_fill["numa_bound"] = "NUMA-bound" in out.stderr
+                r["fill_threads_%d" % T] = round(world / slowest, 1)                        # the slowest rank's rate x ranks
+                r["numa_bound"] = "NUMA-bound" in out.stderr
             barrier()
-        end_to_end = {"value": round(world * S / dt, 1), "unit": "sectors/s", "slots": SLOTS, "sectors_per_gpu": S,
-                      "with_host_fill": with_fill,
-                      "ingest": f"wire format, 12 B/sample big-endian int16 ({m * n * 12 / 2**20:g} MiB/sector), decoded on the GPU",
-                      "h2d_GBps_per_gpu": round(S * m * n * 12 / dt / 1e9, 1), "spot_check_vs_oracle": e_ok,
-                      "includes": "pinned H2D + decode + range/Doppler kernels + D2H per sector; host refill of the pinned "
-                                  "slots not included"}
+            return r
+
+        # every sector crosses PCIe: wire-format sector in the slot's pinned buffer -> H2D -> decode -> chain -> D2H of 4 KiB,
+        # 4 slots cascading, all ranks at once.  `value`: 8 bytes per sample (WRP_FLAG_WIRE_8: the feeder has dropped VH, which
+        # no output reads); `wire12`: the reference's 12-byte sample as it arrives
+        e12 = cascade(eng, 12)
+        with wrp_amd.Engine(device=dev_index, n_slots=SLOTS, n_sectors=S, n_elevations=1, m=m, n=n, flags=wrp_amd.FLAG_WIRE_8) as e8:
+            e8r = cascade(e8, 8)
+        e12["with_host_fill"] = host_fill(12)
+        end_to_end = dict(e8r, slots=SLOTS, sectors_per_gpu=S, with_host_fill=host_fill(8), wire12=e12,
+                          ingest=f"WRP_FLAG_WIRE_8: 8 B/sample big-endian int16, hh + vv ({m * n * 8 / 2**20:g} MiB/sector), decoded on the GPU; "
+                                 f"wire12: the 12-byte sample with VH ({m * n * 12 / 2**20:g} MiB/sector)",
+                          includes="pinned H2D + decode + range/Doppler kernels + D2H per sector; host refill of the pinned slots not "
+                                   "included (with_host_fill: rpv2 --in synthetic:copy:T [--wire8] --bind-numa --out none -- pageable -> pinned "
+                                   "copy by T host thread(s) + everything else, all ranks at once)")
+
+    # batches on a CALLER's stream (INTEGRATION.md's production form): behind every fused launch the gated two-kernel repeat is
+    # queued (include/wrp.h: stream order alone); its cost when the launch has succeeded -- the usual case -- is what this
+    # sweep shows against the headline (ADVICE r04)
+    caller = None
+    if not args.no_extras:
+        st = torch.cuda.Stream(device=dev)
+        caller = {"unit": "sectors/s", "what": "the headline sweep, and the 12-byte wire-format sweep, on a caller's stream: fused launch + its "
+                  "gated repeat (decode / range / Doppler grids that return at once) per batch; wall clock over <= 100 batches"}
+        d_raw = torch.from_numpy(wire_pool(pool, 12)).to(dev)[torch.arange(S, device=dev) % 8].contiguous()
+        d_o = torch.empty_like(d_out)
+        for name, fn, src in (("planar", eng.process_batch_device, d_iq), ("wire12", eng.process_batch_raw_device, d_raw)):
+            for _ in range(max(args.warmup, 10)):
+                fn(src.data_ptr(), S, d_o.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+            steps = max(10, min(args.steps, 100))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn(src.data_ptr(), S, d_o.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+            eng.check()
+            barrier()
+            caller[name] = round(world * S * steps / max_over_ranks(time.perf_counter() - t0), 1)
+            caller[name + "_bit_identical"] = bool(torch.equal(d_o, d_out))
+        caller["fused_fallbacks"] = eng.fused_fallbacks
+        del d_raw, d_o
 
     total_sectors = world * S * args.steps
     line = {
@@ -533,7 +570,12 @@ def main():
                                (f"shape B = BASELINE configs[4] (C=2, m=2048 range gates, n=128 pulses, fp32 complex), {S} sectors "
                                 f"per GPU per step, device-resident"), "sectors_per_step_per_gpu": S,
                    "parallelism": f"sector-sharded x{world}, no collective (barrier + MAX of the elapsed time over a TCP store)",
-                   "launch": "fused" if fused else "two kernels", "untimed_settle_s": args.settle},
+                   "launch": "fused" if fused else "two kernels", "untimed_settle_s": args.settle,
+                   # a7 (read.cc:290-301) in the timed launch, said in so many words
+                   "ma_stage": "row sum as the DC bin of the circular moving average: S = (sum of the taps) x (sum |.|^2); the stage "
+                               "08pow itself (direct causal circular 7-tap) is formed by the dump instantiations only -- every ma_count "
+                               "stage-tested in tests/test_gpu_batches.py; forming it in the timed launch costs +0.97 % (1024 x 512), "
+                               "+0.59 % (wire format), +0.27 % (2048 x 128): profiles/r04/ab_rowsum_dc_bin.log"},
         "achieved_hbm_GBps": round(world * achieved, 1),
         "spot_check_vs_oracle": ok,
         "single_sector_latency_us": single["submit_wait_pinned_us"] if single else None,
@@ -546,6 +588,8 @@ def main():
         line["shape_b"] = shape_b
     if end_to_end is not None:
         line["end_to_end"] = end_to_end
+    if caller is not None:
+        line["caller_stream"] = caller
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(m, n)
     eng.close()

@@ -1,0 +1,38 @@
+#!/bin/bash
+# profiles/rNN/floor[_B].json: the fused launch with every request of its input DROPPED by the descriptor (zero records: the
+# loads return at once, the results are wrong on purpose) -- what the launch costs when the input costs nothing.  A timing
+# build of the CURRENT sources (a copy of csrc/ with the descriptors' sizes set to 0), timed in one process beside the
+# product build with tools/ab.py --no-check.  Part 1 (here, needs hipcc): tools/make_floor.sh build; part 2 (GPU box):
+# tools/make_floor.sh run rNN
+set -eu
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+L=$ROOT/build/floor
+if [ "${1:-}" = build ]; then
+  rm -rf $L; mkdir -p $L/pkg/csrc $L/include
+  cp $ROOT/include/wrp.h $L/include/; cp $ROOT/weather-radar-processing_amd/csrc/* $L/pkg/csrc/
+  # every descriptor of the INPUT (tile loads of both launches and both formats, the row waves' touches): never valid
+  sed -i -E '/make_rsrc\((src|sector_raw|range), valid \?/s/valid \?/false \&\& valid ?/' $L/pkg/csrc/wrp_fused.h $L/pkg/csrc/wrp_fused_b.h
+  grep -c "false && valid" $L/pkg/csrc/wrp_fused.h $L/pkg/csrc/wrp_fused_b.h
+  FLAGS=$(grep '^HIPFLAGS' $ROOT/Makefile | sed 's/.*?= //; s/\$(ARCH)/gfx950/')
+  /opt/rocm/bin/hipcc $FLAGS -shared -o $L/libwrp_noinput.so $L/pkg/csrc/wrp_engine.hip
+  cp $ROOT/weather-radar-processing_amd/lib/libwrp.so $L/libwrp_product.so
+  ls -la $L/*.so
+else
+  R=${1:-r05}; OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
+  cd $ROOT
+  python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so --rounds 20 --no-check > $OUT/floor_A.log 2>&1
+  python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so --rounds 20 --no-check --shape B > $OUT/floor_B.log 2>&1
+  python3 - $OUT <<'PY'
+import json, re, sys, os
+sys.path.insert(0, os.getcwd())
+import wrp_amd
+out = sys.argv[1]
+for shape, name in (("A", "floor.json"), ("B", "floor_B.json")):
+    t = open(f"{out}/floor_{shape}.log").read()
+    med = dict(re.findall(r"(libwrp_\w+)\.so\s+ok=\w+\s+median\s+([0-9.]+)", t))
+    json.dump({"source": f"tools/make_floor.sh ({out}/floor_{shape}.log): tools/ab.py --no-check, the product build and a timing build of the same sources whose input descriptors have zero records",
+               "fingerprint": wrp_amd.source_fingerprint(), "us_per_sector": float(med["libwrp_product"]),
+               "no_input_us_per_sector": float(med["libwrp_noinput"])}, open(f"{out}/{name}", "w"), indent=1)
+    print(shape, med)
+PY
+fi

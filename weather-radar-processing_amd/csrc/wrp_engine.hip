@@ -43,6 +43,8 @@ struct Slot {
 constexpr int WRP_RING = 64;            // fused batches that may be outstanding (status words, events)
 constexpr int WRP_FUSED_COOLDOWN = 16;  // batches on the two-kernel path after a fused launch that gave up
 constexpr int WRP_DECODE_MIN = 8;       // smallest decode workspace (sectors): it grows on demand up to max_batch sectors
+constexpr int WRP_GATED_ROWS = 2;       // workgroup rows (grid.y) of a GATED decode / Doppler launch: it walks its sectors with them
+constexpr int WRP_GATED_DECODE = 128;   // sectors a gated repeat decodes at a time: it never grows the decode workspace beyond this
 
 struct FusedLane {
     wrp::FusedCtl *d_ctl = nullptr;
@@ -231,9 +233,10 @@ void launch_doppler_t(wrp_engine *h, const float2 *d_mid, int n_sectors, float *
                       const wrp::DumpPtrs &d, const unsigned *gate)
 {
     const wrp_config &c = h->cfg;
-    const dim3 grid(c.m / 2 / wrp::DP_WAVES, n_sectors), block(wrp::DP_WAVES * 64);
+    // a gated launch almost never has anything to do: a few rows of workgroups that would walk the sectors
+    const dim3 grid(c.m / 2 / wrp::DP_WAVES, gate ? std::min(n_sectors, WRP_GATED_ROWS) : n_sectors), block(wrp::DP_WAVES * 64);
     hipLaunchKernelGGL((wrp::doppler_pass_512<DUMP, TAPS>), grid, block, 0, st, d_mid, d_out, h->d_tw_n_arr,
-                       c.m / 2, h->taps, c.k_range_resolution, c.k_calibration, d, gate);
+                       c.m / 2, n_sectors, h->taps, c.k_range_resolution, c.k_calibration, d, gate);
 }
 
 // frames + frame_hdr: the slot path (sector 0 of the launch); fr: the batch entries (every sector, header table)
@@ -248,9 +251,9 @@ void launch_doppler(wrp_engine *h, const float2 *d_mid, int n_sectors, float *d_
     none.frame_hdrs = fr.frames ? fr.hdrs : nullptr;
     if (h->tuned_b && !(dump && (dump->hamm || dump->fft1))) {
         const wrp_config &c = h->cfg;
-        const dim3 grid(c.m / 2 / (wrp::DB_WAVES * 2), n_sectors), block(wrp::DB_WAVES * 64);
+        const dim3 grid(c.m / 2 / (wrp::DB_WAVES * 2), gate ? std::min(n_sectors, WRP_GATED_ROWS) : n_sectors), block(wrp::DB_WAVES * 64);
 #define WRP_DOPPLER_B(TAPS, DUMP)                                                                                    \
-    hipLaunchKernelGGL((wrp::doppler_pass_128<TAPS, DUMP>), grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, h->taps, \
+    hipLaunchKernelGGL((wrp::doppler_pass_128<TAPS, DUMP>), grid, block, 0, st, d_mid, d_out, h->d_tw_n, c.m / 2, n_sectors, h->taps, \
                        c.k_range_resolution, c.k_calibration, dump ? *dump : none, gate)
         if (h->taps_pad == 7) { if (dump) WRP_DOPPLER_B(7, true); else WRP_DOPPLER_B(7, false); }
         else { if (dump) WRP_DOPPLER_B(9, true); else WRP_DOPPLER_B(9, false); }
@@ -386,10 +389,12 @@ int launch_two_kernel_batch(wrp_engine *h, const float2 *in, int n_sectors, floa
     return rc != WRP_OK ? rc : workspace_release(h, st);
 }
 
-// the decode workspace holds at least `sectors` sectors (at most max_batch are ever asked for); growing it waits for the device
-int ensure_decode(wrp_engine *h, int sectors)
+// the decode workspace holds at least `sectors` sectors (at most `limit`, itself at most max_batch, are ever asked for);
+// growing it waits for the device
+int ensure_decode(wrp_engine *h, int sectors, int limit = 1 << 30)
 {
-    sectors = std::min(h->max_batch, std::max(sectors, std::min(h->max_batch, WRP_DECODE_MIN)));
+    limit = std::min(limit, h->max_batch);
+    sectors = std::min(limit, std::max(sectors, std::min(limit, WRP_DECODE_MIN)));
     if (h->decode_cap >= sectors) return WRP_OK;
     if (h->d_decode) {
         HIP_TRY(h, hipDeviceSynchronize());
@@ -405,11 +410,11 @@ int ensure_decode(wrp_engine *h, int sectors)
 void launch_decode(wrp_engine *h, const unsigned char *raw, float2 *dst, int cnt, hipStream_t st, const unsigned *gate = nullptr)
 {
     const int count = h->cfg.m * h->cfg.n;
-    const dim3 grid((count + 255) / 256, cnt), block(256);
+    const dim3 grid((count + 255) / 256, gate ? std::min(cnt, WRP_GATED_ROWS) : cnt), block(256);
     if (h->wire_bytes == 8)
-        hipLaunchKernelGGL(wrp::decode_wire<8>, grid, block, 0, st, (const unsigned *)raw, dst, count, h->cfg.channels, gate);
+        hipLaunchKernelGGL(wrp::decode_wire<8>, grid, block, 0, st, (const unsigned *)raw, dst, count, h->cfg.channels, cnt, gate);
     else
-        hipLaunchKernelGGL(wrp::decode_wire<12>, grid, block, 0, st, (const unsigned *)raw, dst, count, h->cfg.channels, gate);
+        hipLaunchKernelGGL(wrp::decode_wire<12>, grid, block, 0, st, (const unsigned *)raw, dst, count, h->cfg.channels, cnt, gate);
 }
 
 // a wire-format batch on the two-kernel path: decode_wire + the two kernels, as many sectors at a time as both workspaces hold
@@ -418,7 +423,9 @@ int launch_two_kernel_raw_batch(wrp_engine *h, const unsigned char *raw, int n_s
 {
     const wrp_config &c = h->cfg;
     const size_t count = (size_t)c.m * c.n;
-    int rc = ensure_decode(h, n_sectors);
+    // a gated repeat works through whatever the workspace holds (submit_fused_piece has made sure of WRP_GATED_DECODE sectors
+    // BEFORE its launch): nothing here can fail or wait between a fused launch and its repeat
+    int rc = gate ? (h->decode_cap > 0 ? WRP_OK : WRP_ERR_STATE) : ensure_decode(h, n_sectors);
     if (rc == WRP_OK) rc = workspace_acquire(h, st);
     for (int s0 = 0; rc == WRP_OK && s0 < n_sectors; s0 += h->decode_cap) {
         const int cnt = std::min(h->decode_cap, n_sectors - s0);    // decode_cap <= max_batch: d_mid holds them too
@@ -493,33 +500,47 @@ int reap_fused(wrp_engine *h, bool block, size_t leave = 0)
 // device memory (its workgroups return at once when the launch has succeeded): d_out is right when the stream says so,
 // whether or not the host ever looks (stream order alone; include/wrp.h).  On the engine's own stream nothing but
 // wrp_check can wait for the batch, and wrp_check repeats a failed launch itself: no gated launches there.
+int two_kernel_batch(wrp_engine *h, const void *in, bool raw, int n_sectors, float *d_out, hipStream_t st, Frames fr);
+
 int submit_fused_piece(wrp_engine *h, const float2 *in, int n_sectors, float *d_out, hipStream_t stream, bool raw, Frames fr)
 {
     hipStream_t st = stream ? stream : h->stream;
     if (h->outstanding.size() >= (size_t)WRP_RING) {
         const int rc = reap_fused(h, true, WRP_RING - 1);
         if (rc != WRP_OK) return rc;
-        if (!h->fused_armed)      // one of them had given up: this batch takes the two kernels
-            return raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, st, fr)
-                       : launch_two_kernel_batch(h, in, n_sectors, d_out, st, fr);
+        if (!h->fused_armed) return two_kernel_batch(h, in, raw, n_sectors, d_out, st, fr);   // one of them had given up
     }
     FusedLane &lane = h->lane;
+    // Everything that can fail or wait on the host comes BEFORE the launch: the decode workspace of the gated
+    // repeat.  Behind the launch there are only stream operations, and the launch is on the books before the first of them.
+    if (stream && raw) {
+        const int rc = ensure_decode(h, std::min(n_sectors, WRP_GATED_DECODE), WRP_GATED_DECODE);
+        if (rc != WRP_OK) return rc;
+    }
     if (lane.used) HIP_TRY(h, hipStreamWaitEvent(st, lane.done, 0));   // control block and slots are free again (free on one stream)
     const int slot = h->ring_next;
-    h->ring_next = (h->ring_next + 1) % WRP_RING;
     int rc = launch_fused(h, lane, in, n_sectors, d_out, st, slot, nullptr, raw, fr);
-    if (rc != WRP_OK) return rc;
+    if (rc != WRP_OK) return rc;                                       // nothing was queued
+    h->ring_next = (h->ring_next + 1) % WRP_RING;
     h->fused_launches++;
-    HIP_TRY(h, hipEventRecord(h->ev_ring[slot], st));
+    // on the books: whatever fails below, the launch is waited for (reap_fused, wrp_destroy), its status word is read and
+    // zeroed, and the next launch on this lane waits for it
+    const hipError_t e_ring = hipEventRecord(h->ev_ring[slot], st), e_lane = hipEventRecord(lane.done, st);
+    lane.used = true;
+    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, raw, stream != nullptr, fr});
+    if (e_ring != hipSuccess || e_lane != hipSuccess) {
+        (void)hipStreamSynchronize(st);                                // no event to wait on: wait here
+        HIP_TRY(h, e_ring != hipSuccess ? e_ring : e_lane);
+    }
     if (stream) {
         const unsigned *gate = &lane.d_ctl->status;
         rc = raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, st, fr, gate)
                  : launch_two_kernel_batch(h, in, n_sectors, d_out, st, fr, gate);
+        // the gated launches read the control block: the lane is free behind THEM
+        const hipError_t e = hipEventRecord(lane.done, st);
         if (rc != WRP_OK) return rc;
+        HIP_TRY(h, e);
     }
-    HIP_TRY(h, hipEventRecord(lane.done, st));
-    lane.used = true;
-    h->outstanding.push_back(FusedBatch{in, n_sectors, d_out, slot, raw, stream != nullptr, fr});
     return WRP_OK;
 }
 
@@ -871,6 +892,19 @@ int wrp_result_frame(wrp_handle h, int sector, int elevation, int which, int wit
     return WRP_OK;
 }
 
+// a batch on the two kernels; while the fused launch is disarmed (one gave up) every such batch of fused size counts down
+// to its next chance
+namespace {
+int two_kernel_batch(wrp_engine *h, const void *in, bool raw, int n_sectors, float *d_out, hipStream_t st, Frames fr)
+{
+    const int rc = raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)in, n_sectors, d_out, st, fr)
+                       : launch_two_kernel_batch(h, (const float2 *)in, n_sectors, d_out, st, fr);
+    if (rc == WRP_OK && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
+        h->fused_armed = true;     // the fused launch gets another chance
+    return rc;
+}
+} // namespace
+
 // one batch, planar or wire format, with or without framed products: the fused launch where the shape, the size and the
 // handle's state allow it, the two kernels otherwise
 static int process_batch(wrp_handle h, const void *d_in, bool raw, int n_sectors, float *d_out, Frames fr, void *stream)
@@ -882,12 +916,7 @@ static int process_batch(wrp_handle h, const void *d_in, bool raw, int n_sectors
     int rc = reap_fused(h, false);
     if (rc != WRP_OK) return rc;
     if (h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS) return submit_fused(h, (const float2 *)d_in, n_sectors, d_out, (hipStream_t)stream, raw, fr);
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    rc = raw ? launch_two_kernel_raw_batch(h, (const unsigned char *)d_in, n_sectors, d_out, st, fr)
-             : launch_two_kernel_batch(h, (const float2 *)d_in, n_sectors, d_out, st, fr);
-    if (rc == WRP_OK && h->fused && !h->fused_armed && n_sectors >= WRP_FUSED_MIN_SECTORS && --h->fused_cooldown <= 0)
-        h->fused_armed = true;     // the fused launch gets another chance
-    return rc;
+    return two_kernel_batch(h, d_in, raw, n_sectors, d_out, stream ? (hipStream_t)stream : h->stream, fr);
 }
 
 int wrp_process_batch_device(wrp_handle h, const void *d_iq, int n_sectors, float *d_out, void *stream)

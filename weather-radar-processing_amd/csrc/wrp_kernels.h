@@ -603,33 +603,41 @@ __device__ __forceinline__ void reflectivity_store(float *out2, int gate, float 
     }
 }
 
+// gridDim.y = n_sectors: one sector per workgroup row.  The gated repeat of a batch (a launch that almost never has
+// anything to do: wrp_engine.hip, submit_fused_piece) is queued with a few rows only, which walk the sectors.
 template <bool DUMP, int TAPS>
 __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
     const float2 *__restrict__ mid,  // [S][2][gates][512]
     float *__restrict__ out,         // [S][gates][2]
     const float2 *__restrict__ tw,   // [DP_TW_ELEMS] exp(+2 pi i k / 512), arranged (doppler_twiddle_index)
-    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump, const unsigned *gate_word)
+    int gates, int n_sectors, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump, const unsigned *gate_word)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DP_WAVES][DP_ELEMS];
     __shared__ __attribute__((aligned(16))) float2 s_tw[DP_TW_ELEMS];
     if (gate_closed(gate_word)) return;
     const int w = wave_id(), l = threadIdx.x & 63;
     const int gate = blockIdx.x * DP_WAVES + w;
-    const int sec = blockIdx.y;
-    cf x[2][8];                      // both rows in flight before any arithmetic
+    bool tables = false;
+#pragma unroll 1
+    for (int sec = blockIdx.y; sec < n_sectors; sec += gridDim.y) {
+        cf x[2][8];                      // both rows in flight before any arithmetic
 #pragma unroll
-    for (int ch = 0; ch < 2; ch++)
-        doppler_load_row<AUX_NT>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
-    doppler_twiddles_to_lds(s_tw, tw, threadIdx.x, DP_WAVES * 64);
-    __syncthreads();
-    float S[2];
+        for (int ch = 0; ch < 2; ch++)
+            doppler_load_row<AUX_NT>(mid + (((size_t)sec * 2 + ch) * gates + gate) * DP_N, l, x[ch]);
+        if (!tables) {                   // (workgroup-uniform)
+            doppler_twiddles_to_lds(s_tw, tw, threadIdx.x, DP_WAVES * 64);
+            __syncthreads();
+            tables = true;
+        }
+        float S[2];
 #pragma unroll
-    for (int ch = 0; ch < 2; ch++)
-        S[ch] = doppler_row<DUMP, TAPS>(x[ch], lds[w], s_tw, taps, l, gate, DUMP && dump.channel == ch && sec == 0, dump);
-    if (l == 0) {
-        unsigned hdr;
-        unsigned *frames = sector_frames(dump, sec, gates, hdr);
-        reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, frames, gates, hdr);
+        for (int ch = 0; ch < 2; ch++)
+            S[ch] = doppler_row<DUMP, TAPS>(x[ch], lds[w], s_tw, taps, l, gate, DUMP && dump.channel == ch && sec == 0, dump);
+        if (l == 0) {
+            unsigned hdr;
+            unsigned *frames = sector_frames(dump, sec, gates, hdr);
+            reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S[0], S[1], k_rr, k_cal, frames, gates, hdr);
+        }
     }
 }
 
@@ -643,22 +651,24 @@ __global__ __launch_bounds__(DP_WAVES * 64) void doppler_pass_512(
 // (WRP_FLAG_WIRE_8, include/wrp.h): no output reads VH (rpv2.cu:199-213); a third plane of the block is left as it is.
 // =============================================================================================
 template <int WB>
-__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [sectors = gridDim.y][count][WB / 4] dwords
-                                                    float2 *__restrict__ iq,            // [sectors][channels][count]
-                                                    int count, int channels, const unsigned *gate)
+__global__ __launch_bounds__(256) void decode_wire(const unsigned *__restrict__ raw,   // [n_sectors][count][WB / 4] dwords
+                                                    float2 *__restrict__ iq,            // [n_sectors][channels][count]
+                                                    int count, int channels, int n_sectors, const unsigned *gate)
 {
     constexpr int D = WB / 4;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count || gate_closed(gate)) return;
-    raw += (size_t)blockIdx.y * count * D;
-    iq += (size_t)blockIdx.y * channels * count;
-    unsigned w[D];
+    for (int sec = blockIdx.y; sec < n_sectors; sec += gridDim.y) {     // gridDim.y = n_sectors, or a few rows (gated repeat)
+        const unsigned *r = raw + (size_t)sec * count * D;
+        float2 *q = iq + (size_t)sec * channels * count;
+        unsigned w[D];
 #pragma unroll
-    for (int c = 0; c < D; c++) w[c] = __builtin_bswap32(raw[D * t + c]);
+        for (int c = 0; c < D; c++) w[c] = __builtin_bswap32(r[D * t + c]);
 #pragma unroll
-    for (int c = 0; c < D; c++)
-        if (c < channels)
-            iq[(size_t)c * count + t] = make_float2((float)(short)(w[c] >> 16), (float)(short)(w[c] & 0xffffu));
+        for (int c = 0; c < D; c++)
+            if (c < channels)
+                q[(size_t)c * count + t] = make_float2((float)(short)(w[c] >> 16), (float)(short)(w[c] & 0xffffu));
+    }
 }
 
 } // namespace wrp

@@ -336,12 +336,13 @@ __device__ __forceinline__ float doppler_row_128(cf (&v)[8], float2 *buf, const 
     return S;
 }
 
+// gridDim.y = n_sectors, or a few rows that walk the sectors (the gated repeat of a batch: see doppler_pass_512)
 template <int TAPS, bool DUMP = false>
 __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     const float2 *__restrict__ mid,  // [S][2][gates][128]
     float *__restrict__ out,         // [S][gates][2]
     const float2 *__restrict__ tw,   // [128] exp(+2 pi i k / 128)
-    int gates, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump, const unsigned *gate_word)
+    int gates, int n_sectors, MaTaps taps, float k_rr, float k_cal, DumpPtrs dump, const unsigned *gate_word)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[DB_WAVES * 4][DB_ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) float2 s_tw[RB_N];
@@ -349,21 +350,27 @@ __global__ __launch_bounds__(DB_WAVES * 64) void doppler_pass_128(
     const int w = wave_id(), l = threadIdx.x & 63;
     const int sub = l >> 4, i = l & 15;               // sub: 0 (g, HH), 1 (g, VV), 2 (g + 1, HH), 3 (g + 1, VV)
     const int gate = (blockIdx.x * DB_WAVES + w) * 2 + (sub >> 1), ch = sub & 1;
-    const int sec = blockIdx.y;
-    // descriptor on the sector (wave-uniform); the row of this 16-lane group goes into the lane offset
-    const rsrc_t rs = make_rsrc(mid + (size_t)sec * 2 * gates * RB_N, (unsigned)(2 * gates * RB_N) * 8u);
-    const int voff = ((ch * gates + gate) * RB_N + i) * 8;
-    cf x[8];
+    bool tables = false;
+#pragma unroll 1
+    for (int sec = blockIdx.y; sec < n_sectors; sec += gridDim.y) {
+        // descriptor on the sector (wave-uniform); the row of this 16-lane group goes into the lane offset
+        const rsrc_t rs = make_rsrc(mid + (size_t)sec * 2 * gates * RB_N, (unsigned)(2 * gates * RB_N) * 8u);
+        const int voff = ((ch * gates + gate) * RB_N + i) * 8;
+        cf x[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_NT>(rs, voff, 16 * r * 8);
-    for (int e = threadIdx.x; e < RB_N; e += DB_WAVES * 64) s_tw[e] = tw[e];
-    __syncthreads();
-    const float S = doppler_row_128<TAPS, DUMP>(x, lds[w * 4 + sub], s_tw, taps, i, gate, DUMP && dump.channel == ch && sec == 0, dump);
-    const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
-    if (i == 0 && ch == 0) {
-        unsigned hdr;
-        unsigned *frames = sector_frames(dump, sec, gates, hdr);
-        reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal, frames, gates, hdr);
+        for (int r = 0; r < 8; r++) x[r] = buf_load_f2<AUX_NT>(rs, voff, 16 * r * 8);
+        if (!tables) {                   // (workgroup-uniform)
+            for (int e = threadIdx.x; e < RB_N; e += DB_WAVES * 64) s_tw[e] = tw[e];
+            __syncthreads();
+            tables = true;
+        }
+        const float S = doppler_row_128<TAPS, DUMP>(x, lds[w * 4 + sub], s_tw, taps, i, gate, DUMP && dump.channel == ch && sec == 0, dump);
+        const float other = __shfl(S, (l + 16) & 63);     // the VV row sum sits 16 lanes above the HH one
+        if (i == 0 && ch == 0) {
+            unsigned hdr;
+            unsigned *frames = sector_frames(dump, sec, gates, hdr);
+            reflectivity_store(&out[((size_t)sec * gates + gate) * 2], gate, S, other, k_rr, k_cal, frames, gates, hdr);
+        }
     }
 }
 

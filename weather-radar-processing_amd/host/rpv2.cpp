@@ -25,6 +25,9 @@
 // reads VH, rpv2.cu:199-213): the copy that brings a sector into its pinned slot -- from the socket's row buffer, the
 // file's staging buffer or synthetic:copy's pageable buffer -- drops bytes 8..11 of every sample (host/wire.h).  The
 // input (socket, file) is the reference's 12-byte format either way.
+// --fill-bench: no sector is processed; times the host's copy of a sector from a pageable buffer into the engine's pinned
+// slots by itself -- plain copy and VH-dropping copy, 1 / 2 / 4 / 8 threads, with and without --bind-numa -- and prints
+// microseconds per sector and GB/s of bytes read (what bounds bench.py's end_to_end.with_host_fill).
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -73,13 +76,56 @@ bool bind_to_gpu_numa(int device)
     return sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
+// --fill-bench (see the header): the copy into the pinned slots by itself
+int run_fill_bench(int device, int slots, bool bind_numa)
+{
+    const bool bound = bind_numa && bind_to_gpu_numa(device);
+    const size_t samples = (size_t)1024 * 512;
+    std::vector<char> pageable(samples * WIRE_BYTES_PER_SAMPLE, 3);
+    for (int wb : {12, 8}) {
+        wrp_config cfg;
+        wrp_default_config(&cfg);
+        cfg.n_slots = slots;
+        cfg.n_sectors = 1;
+        cfg.n_elevations = 1;
+        if (wb == 8) cfg.flags |= WRP_FLAG_WIRE_8;
+        wrp_handle h = nullptr;
+        if (wrp_create(&cfg, device, &h) != WRP_OK) { fprintf(stderr, "fill-bench: wrp_create failed\n"); return 1; }
+        std::vector<char *> slot(slots);
+        for (int s = 0; s < slots; s++) {
+            void *p = nullptr;
+            size_t bytes = 0;
+            if (wrp_pinned_raw_slot(h, s, &p, &bytes) != WRP_OK || bytes != samples * wb) { fprintf(stderr, "fill-bench: slot\n"); return 1; }
+            slot[s] = (char *)p;
+        }
+        for (int T : {1, 2, 4, 8}) {
+            FillPool pool(T);
+            const int reps = 400;
+            double best = 1e30;
+            for (int pass = 0; pass < 3; pass++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int k = 0; k < reps; k++) {
+                    if (wb == 8) pool.drop_vh(slot[k % slots], pageable.data(), samples);
+                    else pool.copy(slot[k % slots], pageable.data(), samples * WIRE_BYTES_PER_SAMPLE);
+                }
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+                if (dt < best) best = dt;
+            }
+            fprintf(stderr, "fill-bench: %2d B/sample into the pinned slot, %d thread(s)%s: %7.1f us per sector = %6.0f sectors/s, %5.1f GB/s read + %5.1f GB/s written\n",
+                    wb, T, bound ? ", NUMA-bound" : "", best * 1e6, 1.0 / best, samples * 12 / best / 1e9, samples * wb / best / 1e9);
+        }
+        wrp_destroy(h);
+    }
+    return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
 {
     int num_streams = 2;
     long sectors = -1;
-    bool with_elev = true, with_elev_set = false, bind_numa = false, wire8 = false;
+    bool with_elev = true, with_elev_set = false, bind_numa = false, wire8 = false, fill_bench = false;
     int scan_sectors = 143, scan_elevations = 9;
     std::vector<int> devices{0};
     std::string in = "udp:19001", out = "udp:19002,19003";
@@ -101,9 +147,11 @@ int main(int argc, char **argv)
         } else if (a == "--no-elevation") { with_elev = false; with_elev_set = true; }
         else if (a == "--bind-numa") bind_numa = true;
         else if (a == "--wire8") wire8 = true;
+        else if (a == "--fill-bench") fill_bench = true;
         else if (a[0] != '-') { num_streams = atoi(a.c_str()); if (num_streams < 1) num_streams = 1; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
+    if (fill_bench) return run_fill_bench(devices[0], num_streams < 4 ? 4 : num_streams, bind_numa);
     const int G = (int)devices.size();
     std::vector<std::unique_ptr<RadarProcessor>> procs;
     SectorTurnstile turn;
