@@ -502,13 +502,13 @@ def main():
             import re
             if args.shape != "A" or not os.path.exists(rpv2):
                 return None
-            r = {"unit": "sectors/s"}
-            for T in (1, 4):
+            r = {"unit": "sectors/s", "what": "steady state: the rate past the run's first 128 sectors (first use of kernels and pinned buffers)"}
+            for T in (1, 2, 4):
                 barrier()
                 out = subprocess.run([rpv2, str(SLOTS), "--device", str(dev_index), "--in", "synthetic:copy:%d" % T, "--bind-numa",
                                       "--out", "none", "--scan", "%d,1" % S, "--sectors", str(3 * S)] + (["--wire8"] if wb == 8 else []),
                                      capture_output=True, text=True, timeout=300)
-                mm_ = re.search(r"\(([0-9.]+) sectors/s end to end", out.stderr)
+                mm_ = re.search(r"steady state .*: ([0-9.]+) sectors/s", out.stderr) or re.search(r"\(([0-9.]+) sectors/s end to end", out.stderr)
                 rate = float(mm_.group(1)) if mm_ else 0.0
                 slowest = max_over_ranks(1.0 / rate if rate > 0 else float("inf"))          # every rank takes part
                 r["fill_threads_%d" % T] = round(world / slowest, 1)                        # the slowest rank's rate x ranks

@@ -101,7 +101,9 @@ typedef enum {
     WRP_STAGE_03FFT2 = 4,         /* m/2 x n complex after conj + shift + clip        (a5) */
     WRP_STAGE_04ABS = 5,          /* m/2 x n real   |.|^2                             (a6) */
     WRP_STAGE_08POW = 6,          /* m/2 x n real   MA-smoothed power                 (a7) */
-    WRP_STAGE_ROWSUM = 7,         /* m/2 real       S[i]                              (a8) */
+    WRP_STAGE_ROWSUM = 7,         /* m/2 real       S[i] (a8) AS THE CHAIN FORMS IT: (sum of the taps) x (sum over j of 04ABS[i][j]) --
+                                     the row sum of the CIRCULAR moving average is its DC bin (read.cc:290-301, 336-339) -- and NOT the
+                                     sum of the dumped 08POW row, from which it differs by rounding only (tested: <= 2e-6 relative) */
     WRP_STAGE_MID = 8             /* m/2 x n complex: the half-height intermediate exactly as the production range pass of
                                      the two-kernel path hands it to the Doppler pass (= rows < m/2 of 02FFT1; no dump
                                      instantiation involved) */

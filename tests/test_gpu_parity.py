@@ -377,6 +377,23 @@ def test_rowsum_obeys_parseval_identity(engine, sectors, oracle_s0):
     assert np.max(np.abs(S - ident) / ident) < 1e-5
 
 
+def test_rowsum_dump_ties_to_the_pow_dump(engine, sectors):
+    """WRP_STAGE_ROWSUM is S as the chain forms it -- (sum of the taps) x (sum of 04abs): the DC bin of the circular moving
+    average (include/wrp.h) -- not the sum of the dumped 08pow row: the two dumps must still agree to rounding,
+    and S with the dumped |.|^2 row exactly as the formula says."""
+    engine.slot_array(0)[:] = sectors[1]
+    engine.submit(0, 0, 0)
+    engine.wait(0)
+    for ch in (0, 1):
+        S = engine.dump_stage(0, "rowsum", ch).astype(np.float64)
+        pw = engine.dump_stage(0, "08pow", ch).astype(np.float64)
+        ab = engine.dump_stage(0, "04abs", ch).astype(np.float64)
+        assert np.max(np.abs(S - pw.sum(axis=1)) / S) < 2e-6
+        g = np.exp(-((np.arange(7) - 3) ** 2) / 2.0)
+        taps_sum = float(np.sum((g / g.sum()).astype(np.float32).astype(np.float64)))
+        assert np.max(np.abs(S - taps_sum * ab.sum(axis=1)) / S) < 1e-6
+
+
 def test_call_order_errors(engine, sectors):
     assert engine.lib.wrp_wait(engine.handle, 0) == -5          # nothing submitted
     engine.slot_array(0)[:] = sectors[0]

@@ -19,7 +19,11 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--sectors", type=int, default=400)
     ap.add_argument("--raw", type=int, default=0)
+    ap.add_argument("--torch-first", action="store_true", help="import torch first: libwrp.so then binds to the HIP runtime bundled with torch (what bench.py runs on) instead of /opt/rocm's")
     a = ap.parse_args()
+    if a.torch_first:
+        import torch
+        torch.cuda.init()
     import numpy as np
     import wrp_amd
     from oracle import oracle as O
@@ -47,6 +51,8 @@ def main():
     want = O.sector(iq[0], iq[1], dtype=np.float64)
     ok = np.max(np.abs(eng.result(a.sectors - 1, 0)[1:] - want[1:])) < 1e-3
     mb = (1024 * 512 * 12 if a.raw else eng.sector_bytes) / 1e6
+    hip = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]
+    print("HIP runtime:", sorted(set(hip)))
     print(f"{'raw int16 wire' if a.raw else 'fp32 planar'} ingest, {a.slots} slots: {a.sectors / dt:8.0f} sectors/s "
           f"end to end ({mb:.1f} MB/sector -> {a.sectors / dt * mb / 1e3:.1f} GB/s over PCIe), ok={ok}")
     eng.close()

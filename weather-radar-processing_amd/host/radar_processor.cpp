@@ -189,10 +189,18 @@ void RadarProcessor::do_process()
     current_sector = shard_rank_;
     if (current_sector >= n_sectors) more = false;          // more GPUs than sectors: nothing to do here
     const bool own_budget = turn_ == nullptr;               // sharded: the budget is global, read_matrix enforces it
+    typedef std::chrono::steady_clock clk;
+    auto since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
+    clk::time_point t_warm;
     while (status_ == WRP_OK && (more || !q.empty())) {
         if (more && (int)q.size() < n_streams && (!own_budget || max_sectors_ < 0 || done_ + (long)q.size() < max_sectors_)) {
-            if (read_matrix(current_sector, current_elevation, current_stream) && status_ == WRP_OK) {
+            auto t0 = clk::now();
+            const bool got = read_matrix(current_sector, current_elevation, current_stream);
+            spent_.source += since(t0);
+            if (got && status_ == WRP_OK) {
+                t0 = clk::now();
                 copy_matrix_to_device(current_sector, current_elevation, current_stream);
+                spent_.submit += since(t0);
                 perform_stage_1(current_stream);
                 perform_stage_2(current_stream);
                 perform_stage_3(current_stream);
@@ -206,12 +214,18 @@ void RadarProcessor::do_process()
         if (q.empty()) break;
         const InFlight f = q.front();
         q.erase(q.begin());
+        auto t0 = clk::now();
         copy_result_to_host(f.sector, f.elevation, f.stream);
+        spent_.wait += since(t0);
         if (status_ != WRP_OK) break;
+        t0 = clk::now();
         send_results(f.sector, f.elevation);
+        spent_.sink += since(t0);
         done_++;
+        if (done_ == kWarmSectors) t_warm = clk::now();
         if (own_budget && max_sectors_ >= 0 && done_ + (long)q.size() >= max_sectors_) more = false;
     }
+    if (done_ > kWarmSectors) steady_ = (double)(done_ - kWarmSectors) / since(t_warm);
 }
 
 void RadarProcessor::destroy_streams() {}

@@ -71,6 +71,14 @@ class RadarProcessor {
     void set_frame_with_elevation(bool on) { with_elevation_ = on; }
     long sectors_done() const { return done_; }
     double processing_seconds() const { return seconds_; }   // wall clock of do_process (engine set-up excluded)
+    // where the feeder thread spent that time: in the source (read_matrix), queuing work (wrp_submit_raw), waiting for a
+    // slot (wrp_wait) and in the sink (send_results)
+    struct Breakdown { double source = 0, submit = 0, wait = 0, sink = 0; };
+    Breakdown breakdown() const { return spent_; }
+    // sectors per second once the first kWarmSectors are through (a run's first sectors pay for the first use of every
+    // kernel and of every pinned buffer: ~15 ms, a tenth of a 1000-sector run); 0 when the run was shorter
+    static const long kWarmSectors = 128;
+    double steady_rate() const { return steady_; }
     const char *last_error() const;
 
     const int input_ary_size, input_columns, input_rows, output_ary_size, output_columns, output_rows;
@@ -91,6 +99,8 @@ class RadarProcessor {
     long laps_ = 0;       // completed passes over the elevations (the global sequence number keeps growing)
     long max_sectors_ = -1, done_ = 0;
     double seconds_ = 0;
+    Breakdown spent_;
+    double steady_ = 0;
     bool with_elevation_ = true;
     int status_ = 0;
     int wire_bytes_ = 12;

@@ -281,5 +281,14 @@ int main(int argc, char **argv)
                      dt, total / dt, G, G > 1 ? "s" : "", num_streams,
                      copy_source ? (std::string(", host fill by ") + std::to_string(fill_threads) + " thread(s) per GPU" + (wire8 ? ", VH dropped (8 bytes per sample)" : "")).c_str() : "",
                      bind_numa ? (bound[0] ? ", NUMA-bound" : ", NUMA binding not possible") : "");
+    if (!rc && total > 0) {      // the feeder thread's time per sector, by what it was doing (GPU thread 0)
+        const RadarProcessor::Breakdown b = procs[0]->breakdown();
+        const double k = 1e6 / (double)procs[0]->sectors_done();
+        fprintf(stderr, "rpv2: feeder thread, us per sector: source %.1f, submit %.1f, wait %.1f, sink %.1f (of %.1f)\n", b.source * k, b.submit * k,
+                b.wait * k, b.sink * k, procs[0]->processing_seconds() * k);
+        double steady = 0;     // all GPU threads, each past its first sectors (the first use of kernels and pinned buffers excluded)
+        for (auto &p : procs) steady += p->steady_rate();
+        if (steady > 0) fprintf(stderr, "rpv2: steady state (each GPU thread past its first %ld sectors): %.0f sectors/s\n", RadarProcessor::kWarmSectors, steady);
+    }
     return rc;
 }
