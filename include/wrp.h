@@ -201,7 +201,8 @@ int wrp_process_batch_raw_framed_device(wrp_handle h, const void *d_raw, int n_s
  * The fused launch needs all its workgroups resident at once and says so, within milliseconds, when they
  * are not (e.g. another kernel occupies CUs); such a batch is REPEATED on the two-kernel path:
  *   - a batch given a CALLER's stream: the repeat is queued on that stream right behind the launch, gated on the
- *     launch's status word in device memory (it costs a few microseconds when the launch has succeeded).  STREAM ORDER
+ *     launch's status word in device memory (when the launch has succeeded its kernels are a few workgroup rows that return
+ *     at once: 2 % of a 360-sector batch, bench.py `caller_stream`).  STREAM ORDER
  *     IS ENOUGH: when the stream has passed the batch, d_out (and d_frames) are right, and d_iq / d_raw may be
  *     reused -- like any other asynchronous work on a stream; wrp_check is not needed for correctness.
  *   - a batch on the engine's own stream (stream = NULL): only this library can wait for that stream.  wrp_check (or the

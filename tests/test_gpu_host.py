@@ -94,14 +94,17 @@ def test_rpv2_two_gpu_threads_share_one_source(tmp_path, oracle):
         assert np.max(np.abs(zdr - w[:, 1])) < 2e-5
 
 
-def test_rpv2_udp_ingest_and_egress_on_loopback(oracle):
+@pytest.mark.parametrize("wire8", [False, True])
+def test_rpv2_udp_ingest_and_egress_on_loopback(oracle, wire8):
     """N3, the UDP half: m datagrams of 12 n bytes per sector to port IN (read_single.cc:145-148), products back as
-    one datagram per product with the 2-byte sector header (read_single.cc:510-520), here unicast to 127.0.0.1."""
+    one datagram per product with the 2-byte sector header (read_single.cc:510-520), here unicast to 127.0.0.1.
+    wire8: the same datagrams; every row goes from the socket's buffer into the pinned slot without its VH samples
+    (RadarProcessor::set_comms with WRP_FLAG_WIRE_8)."""
     import socket
     import threading
     import time
     assert os.path.exists(RPV2), "run `make host`"
-    IN, ZDB, ZDR, K = 19411, 19412, 19413, 3
+    IN, ZDB, ZDR, K = (19421, 19422, 19423, 3) if wire8 else (19411, 19412, 19413, 3)
     sectors = [oracle.synthetic_sector(s) for s in range(K)]
     rx = []
     for port in (ZDB, ZDR):
@@ -109,7 +112,7 @@ def test_rpv2_udp_ingest_and_egress_on_loopback(oracle):
         s.bind(("127.0.0.1", port))
         s.settimeout(60)
         rx.append(s)
-    proc = subprocess.Popen([RPV2, "2", "--in", f"udp:{IN}", "--out", f"udp:{ZDB},{ZDR}@127.0.0.1", "--sectors", str(K)],
+    proc = subprocess.Popen([RPV2, "2", "--in", f"udp:{IN}", "--out", f"udp:{ZDB},{ZDR}@127.0.0.1", "--sectors", str(K)] + (["--wire8"] if wire8 else []),
                             stderr=subprocess.PIPE, text=True)
     got = {0: [], 1: []}
 
