@@ -541,9 +541,11 @@ def main():
         d_raw = torch.from_numpy(wire_pool(pool, 12)).to(dev)[torch.arange(S, device=dev) % 8].contiguous()
         d_o = torch.empty_like(d_out)
         for name, fn, src in (("planar", eng.process_batch_device, d_iq), ("wire12", eng.process_batch_raw_device, d_raw)):
-            for _ in range(max(args.warmup, 10)):
-                fn(src.data_ptr(), S, d_o.data_ptr(), stream=st.cuda_stream)
-            st.synchronize()
+            t_end = time.perf_counter() + max(args.settle, 0.05)     # the GPU has idled through the end-to-end runs: clocks back up, untimed
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    fn(src.data_ptr(), S, d_o.data_ptr(), stream=st.cuda_stream)
+                st.synchronize()
             steps = max(10, min(args.steps, 100))
             barrier()
             t0 = time.perf_counter()

@@ -18,7 +18,7 @@ if [ "${1:-}" = build ]; then
   cp $ROOT/weather-radar-processing_amd/lib/libwrp.so $L/libwrp_product.so
   ls -la $L/*.so
 else
-  R=${1:-r05}; OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
+  R=${2:-r05}; OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
   cd $ROOT
   python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so --rounds 20 --no-check > $OUT/floor_A.log 2>&1
   python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so --rounds 20 --no-check --shape B > $OUT/floor_B.log 2>&1
