@@ -40,6 +40,14 @@ def test_bad_arguments_are_rejected_before_any_gpu_call():
         cfg = wrp_amd.binding.default_config(**{field: bad})
         assert lib.wrp_create(C.byref(cfg), 0, C.byref(h)) == -1, field
         assert not h.value
+    # flag bits: the ones include/wrp.h names pass this check (they then fail on the missing GPU, not as INVALID); any other bit is refused
+    for flags, invalid in ((wrp_amd.FLAG_WIRE_8, False), (wrp_amd.FLAG_WIRE_8 | wrp_amd.FLAG_TWO_KERNELS | 16, False),
+                           (0x20000, True), (wrp_amd.FLAG_WIRE_8 | 0x100, True), (3, True)):
+        cfg = wrp_amd.binding.default_config(flags=flags)
+        assert (lib.wrp_create(C.byref(cfg), 0, C.byref(h)) == -1) == invalid, hex(flags)
+        if h.value:                      # (a GPU box: the engine exists)
+            lib.wrp_destroy(h)
+            h = C.c_void_p()
     # a shape without a kernel instantiation is reported as such, not mis-run
     cfg = wrp_amd.binding.default_config(m=1000, n=512)
     assert lib.wrp_create(C.byref(cfg), 0, C.byref(h)) == -4

@@ -55,10 +55,21 @@ __global__ __launch_bounds__(512) void k_rewrite(float *buf, const float *in, fl
         if (MODE & 1)
             for (int off = tid * 16; off < chunk; off += 512 * 16)
                 acc += __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 16));
-        if (MODE & 2) {
+        if ((MODE & 2) && aux_sel == 6) {
+            // the 2048 x 128 launch's input pattern (round 5): the two workgroups s_slot, s_slot ^ 1 (same XCD when MODE & 4) read
+            // the two 64-byte HALVES of the same 128-byte lines at about the same time, non-temporally: 4 lanes x 16 bytes per row
+            // of 128 bytes, 16 rows per wave-instruction; every line is asked for twice
+            const char *src = reinterpret_cast<const char *>(in) + ((size_t)r * gridDim.x + (s_slot & ~1u)) * stream;
+            const rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src), 0, 2 * stream, 0x00020000);
+            const int half = s_slot & 1;
+            for (int row = tid >> 2; row < 2 * stream / 128; row += 128) {
+                const v4u t = __builtin_amdgcn_raw_buffer_load_b128(ri, row * 128 + half * 64 + (tid & 3) * 16, 0, 2);
+                acc += __builtin_bit_cast(v4f, t);
+            }
+        } else if (MODE & 2) {
             const char *src = reinterpret_cast<const char *>(in) + ((size_t)r * gridDim.x + blockIdx.x) * stream;
             const rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src), 0, stream, 0x00020000);
-            // cache policy of the stream: 0 plain, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc1, 5 sc0 sc1
+            // cache policy of the stream: 0 plain, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc1, 5 sc0 sc1 (6: nt HALF lines by pairs of workgroups, above)
             for (int off = tid * 16; off < stream; off += 512 * 16) {
                 v4u t;
                 switch (aux_sel) {
