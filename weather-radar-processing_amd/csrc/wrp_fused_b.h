@@ -44,6 +44,12 @@ struct FusedTileB {
     static_assert(2 * LDS_BYTES <= 160 * 1024 && 3 * LDS_BYTES > 160 * 1024, "exactly two workgroups per CU");
     // position pos = k1l * 128 + p of the group image, column pair cp (16 bytes)
     static __device__ __forceinline__ int addr(int pos, int cp) { return (pos >> 3) * BLK_BYTES + (pos & 7) * ROW_BYTES + cp * 16; }
+    // In the rows of the positions with bit 1 set the two columns of every pair are swapped (column c sits at (c ^ swz(pos)) * 8).
+    // Stage 1 writes ONE column of a pair at a time, 8 bytes per lane at a 16-byte stride, and a ds_write_b64 serves sixteen
+    // lanes = four 64-byte rows at once: unswapped, the pieces of rows p and p + 2 fall on the same banks (two passes per
+    // write: tools/lds_banks.py model, 256 against 128 LDS cycles per wave and column pair); swapped, they interleave.  Every
+    // other access covers whole rows and only sees its columns permuted (FusedTile::swz is the same idea at 128-byte rows).
+    static __device__ __forceinline__ int swz(int pos) { return (pos >> 1) & 1; }
     // W_2048^{p0 (j + 1)}, j < 8: the eight entries of lane p0 are the 64 bytes of pad p0
     static __device__ __forceinline__ int tw1_addr(int p0, int j) { return p0 * BLK_BYTES + 8 * ROW_BYTES + j * 8; }
     static __device__ __forceinline__ int tw2_addr(int p1, int k2) { return OFF_TW2 + (k2 * 8 + p1) * 8; }
@@ -144,7 +150,7 @@ __device__ __forceinline__ void fused_b_stage1(unsigned char *smem, const float4
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, cp = l & 3;
     const int p0 = w * 16 + (l >> 2);
-    const int slot = T::addr(p0, cp) + 8 * COLUMN;   // position k1*128 + p0 is 16 k1 blocks further on
+    const int slot = T::addr(p0, cp) + 8 * (COLUMN ^ T::swz(p0));   // position k1*128 + p0 is 16 k1 blocks further on (same bit 1)
     const float *s_wr = reinterpret_cast<const float *>(smem + T::OFF_WR);
     float wr[16];    // rows p0 + 128 r; the second half of the window mirrored: wr_c[i] = wr_c[2047 - i]
 #pragma unroll
@@ -173,9 +179,12 @@ __device__ __forceinline__ void fused_b_group1_to_lds(unsigned char *smem, const
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, cp = l & 3;
     const int p0 = w * 16 + (l >> 2);
+    const int first = T::addr(p0, cp) + 8 * T::swz(p0), second = T::addr(p0, cp) + 8 * (1 ^ T::swz(p0));   // two b64 = one b128 in LDS cycles
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        *reinterpret_cast<float4 *>(smem + T::addr(j * 128 + p0, cp)) = make_float4(ga[j].x, ga[j].y, gc[j].x, gc[j].y);
+    for (int j = 0; j < 8; j++) {
+        *reinterpret_cast<float2 *>(smem + first + j * 16 * T::BLK_BYTES) = ga[j];
+        *reinterpret_cast<float2 *>(smem + second + j * 16 * T::BLK_BYTES) = gc[j];
+    }
 }
 
 // stage 2 of the sub-transform this wave owns (image blocks w*16 ..): ONE radix-16 item per lane -- column l & 7,
@@ -187,7 +196,7 @@ __device__ __forceinline__ void fused_b_stage2(unsigned char *smem)
     asm volatile("" : "+v"(tid));
     tid &= FUSED_THREADS - 1;
     const int w = tid >> 6, l = tid & 63, col = l & 7, p1 = l >> 3;
-    unsigned char *base = smem + w * 16 * T::BLK_BYTES + p1 * T::ROW_BYTES + col * 8;
+    unsigned char *base = smem + w * 16 * T::BLK_BYTES + p1 * T::ROW_BYTES + (col ^ T::swz(p1)) * 8;   // positions p1 + 8 r: all of p1's bit 1
     cf a[16], t[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::BLK_BYTES);
@@ -211,10 +220,10 @@ __device__ __forceinline__ void fused_b_stage3(unsigned char *smem, cf (&o)[2][4
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int k2 = (l >> 3) + 8 * it;
-        const unsigned char *base = smem + (w * 16 + k2) * T::BLK_BYTES + col * 8;
+        const unsigned char *base = smem + (w * 16 + k2) * T::BLK_BYTES + col * 8, *base_swz = smem + (w * 16 + k2) * T::BLK_BYTES + (col ^ 1) * 8;
         cf a[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>(base + r * T::ROW_BYTES);
+        for (int r = 0; r < 8; r++) a[r] = *reinterpret_cast<const float2 *>((T::swz(r) ? base_swz : base) + r * T::ROW_BYTES);   // position k2*8 + r
         fft8<-1>(a);
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) o[it][k3] = a[k3];

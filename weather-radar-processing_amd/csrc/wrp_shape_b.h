@@ -209,8 +209,13 @@ __global__ __launch_bounds__(RangeTileB::THREADS, 4) void range_pass_2048(
 
 // ================= Doppler rows of 128 pulses: 16 lanes per row, 128 = 8 x 4 x 4 =================
 constexpr int DB_WAVES = 4;
-constexpr int DB_ROW_ELEMS = 128 + 16;      // complex elements per row buffer: 2 of padding per 16
-__device__ __forceinline__ int db_idx(int pos) { return pos + 2 * (pos >> 4); }
+// Row buffers: ONE element of padding per FOUR, and 1408 bytes from one row's buffer to the next.  A wave holds four rows; its
+// ds_read_b64 are served 32 lanes = two rows at a time over 64 banks, its ds_write_b64 one row at a time over 32: with this
+// map the reads of stages 2 and 3 and the writes of stage 2 take their minimum and the stage-1 writes two passes -- 128 LDS
+// cycles per pass of four rows where 2 per 16 (round 4) took 160 and the minimum is 96 (tools/lds_banks.py model; round 5:
+// SQ_LDS_BANK_CONFLICT was 19 % of the 2048 x 128 launch's LDS-active cycles).
+constexpr int DB_ROW_ELEMS = 176;           // complex elements per row buffer: 128 + 31 of padding, rounded so that rows are 1408 bytes apart
+__device__ __forceinline__ int db_idx(int pos) { return pos + (pos >> 2); }
 __device__ __forceinline__ int db_fidx(int j) { return j + 4 * (j >> 3); }     // as dp_fidx
 
 // sum over the 16 lanes of a DPP row (every lane of the row gets the sum)
