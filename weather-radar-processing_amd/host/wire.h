@@ -3,7 +3,8 @@
 // A sector arrives as 12 bytes per sample: hhI hhQ vvI vvQ vhI vhQ, big-endian int16 (sector.cpp:52-62).  No output reads
 // VH (rpv2.cu:199-213), and the feeder copies every byte once anyway (socket or file -> pinned slot): wire_drop_vh is that
 // copy without bytes 8..11 of every sample, so a sector crosses PCIe as 8 bytes per sample.  The bytes that are kept are
-// not touched (no swap, no conversion: the GPU decodes them, bit-identically to Sector::fromByteArray).
+// not touched (no swap, no conversion: the GPU decodes them, bit-identically to Sector::fromByteArray).  The copy writes with
+// NON-TEMPORAL stores: the slot is read next by the GPU's DMA engine and never again by the CPU.
 //
 // FillPool: the same copy (or a plain memcpy) of one sector split over T threads -- the caller is one of them; the helpers
 // spin for a few microseconds between sectors before they sleep (a sector is ~100 us of copying: a condition-variable
@@ -24,6 +25,9 @@
 // dst8[8 i .. 8 i + 7] = src12[12 i .. 12 i + 7], i < samples.  The buffers must not overlap.
 void wire_drop_vh(unsigned char *dst8, const unsigned char *src12, size_t samples);
 void wire_drop_vh_portable(unsigned char *dst8, const unsigned char *src12, size_t samples);   // the reference loop (tests)
+// memcpy into a pinned slot with non-temporal stores (the 12-byte feeder's copy): the GPU's DMA engine reads the slot next
+// and the CPU never again, so the bytes go past the caches (see wire.cpp)
+void wire_copy_to_pinned(char *dst, const char *src, size_t bytes);
 
 class FillPool {
   public:
