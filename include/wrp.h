@@ -144,7 +144,11 @@ int wrp_submit(wrp_handle h, int slot, int sector, int elevation);
 int wrp_pinned_raw_slot(wrp_handle h, int slot, void **host_ptr, size_t *bytes);
 int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation);
 
-/* Block until the slot's last wrp_submit / wrp_submit_raw has completed. */
+/* Block until the slot's last wrp_submit / wrp_submit_raw has completed.  The call first polls the slot's event for up to
+ * 0.5 ms (a slot's chain takes 0.1 - 0.2 ms; the wake-up of a thread that went to sleep in hipEventSynchronize costs the
+ * cascade more than a sector's transfer takes) and only then sleeps: one feeder thread per GPU, as rpv2.cu:665-683.
+ * The products of the slot path reach the host tables (wrp_result, wrp_result_frame) without a copy: the Doppler pass writes
+ * them into the pinned tables itself. */
 int wrp_wait(wrp_handle h, int slot);
 
 /* Pointer into the host result table result[sitdim(2, m/2, n_sectors, n_elevations)]

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,7 @@ struct Slot {
 constexpr int WRP_RING = 64;            // fused batches that may be outstanding (status words, events)
 constexpr int WRP_FUSED_COOLDOWN = 16;  // batches on the two-kernel path after a fused launch that gave up
 constexpr int WRP_DECODE_MIN = 8;       // smallest decode workspace (sectors): it grows on demand up to max_batch sectors
+constexpr int WRP_WAIT_SPIN_US = 500;   // wrp_wait polls the slot's event this long before it blocks
 constexpr int WRP_GATED_ROWS = 2;       // workgroup rows (grid.y) of a GATED decode / Doppler launch: it walks its sectors with them
 constexpr int WRP_GATED_DECODE = 128;   // sectors a gated repeat decodes at a time: it never grows the decode workspace beyond this
 
@@ -108,6 +110,12 @@ struct wrp_engine {
     std::vector<Slot> slots;
     float *h_result = nullptr; // pinned
     unsigned *h_frames = nullptr;   // pinned [elev][sector][2][1 + m/2]: header word + big-endian floats, as the GPU wrote them
+    // The slot path's Doppler pass writes its 12 KiB of products STRAIGHT into the two pinned tables (their device views):
+    // no D2H copies.  Two API calls fewer per sector on the feeder thread, and nothing of a slot's chain queues on the copy
+    // engine behind the other slots' H2D transfers any more (a 4 KiB D2H behind three 75 us transfers made the C++ feeder
+    // 12 us per sector slower than the link: profiles/r05/feeder_breakdown.log)
+    float *d_result_tab = nullptr;
+    unsigned *d_frames_tab = nullptr;
     // dump scratch
     void *d_dump = nullptr;
     size_t dump_bytes = 0;
@@ -707,11 +715,13 @@ int create_impl(wrp_engine *h)
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_batch, hipEventDisableTiming));
 
     const size_t table = (size_t)c.n_elevations * c.n_sectors * (c.m / 2) * 2;
-    HIP_TRY(h, hipHostMalloc(&h->h_result, sizeof(float) * table, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&h->h_result, sizeof(float) * table, hipHostMallocMapped));
     std::memset(h->h_result, 0, sizeof(float) * table);
+    HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_result_tab, h->h_result, 0));
     const size_t ftable = (size_t)c.n_elevations * c.n_sectors * 2 * (1 + c.m / 2);
-    HIP_TRY(h, hipHostMalloc(&h->h_frames, sizeof(unsigned) * ftable, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&h->h_frames, sizeof(unsigned) * ftable, hipHostMallocMapped));
     std::memset(h->h_frames, 0, sizeof(unsigned) * ftable);
+    HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_frames_tab, h->h_frames, 0));
 
     h->slots.resize(c.n_slots);
     for (auto &s : h->slots) {
@@ -807,11 +817,11 @@ int wrp_submit(wrp_handle h, int slot, int sector, int elevation)
     const wrp_config &c = h->cfg;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(s.d_iq, s.h_iq, sizeof(float2) * sector_elems(c), hipMemcpyHostToDevice, s.stream));
-    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr, s.d_frames, frame_header_word(sector, elevation));
+    // the products go straight into the host tables at (elevation, sector): see d_result_tab
+    const size_t at = (size_t)elevation * c.n_sectors + sector;
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, h->d_result_tab + at * (c.m / 2) * 2, s.stream, nullptr,
+                          h->d_frames_tab + at * 2 * (1 + c.m / 2), frame_header_word(sector, elevation));
     if (rc != WRP_OK) return rc;
-    float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
-    HIP_TRY(h, hipMemcpyAsync(dst, s.d_out, sizeof(float) * (c.m / 2) * 2, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(h, hipMemcpyAsync(frames_of(h, sector, elevation), s.d_frames, sizeof(unsigned) * 2 * (1 + c.m / 2), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(h, hipEventRecord(s.done, s.stream));
     s.busy = true;
     s.loaded = true;
@@ -845,11 +855,11 @@ int wrp_submit_raw(wrp_handle h, int slot, int sector, int elevation)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(s.d_raw, s.h_raw, (size_t)count * h->wire_bytes, hipMemcpyHostToDevice, s.stream));
     launch_decode(h, s.d_raw, s.d_iq, 1, s.stream);
-    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, s.d_out, s.stream, nullptr, s.d_frames, frame_header_word(sector, elevation));
+    // the products go straight into the host tables at (elevation, sector): see d_result_tab
+    const size_t at = (size_t)elevation * c.n_sectors + sector;
+    int rc = launch_chain(h, s.d_iq, 1, s.d_mid, h->d_result_tab + at * (c.m / 2) * 2, s.stream, nullptr,
+                          h->d_frames_tab + at * 2 * (1 + c.m / 2), frame_header_word(sector, elevation));
     if (rc != WRP_OK) return rc;
-    float *dst = h->h_result + ((size_t)elevation * c.n_sectors + sector) * (c.m / 2) * 2;
-    HIP_TRY(h, hipMemcpyAsync(dst, s.d_out, sizeof(float) * (c.m / 2) * 2, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(h, hipMemcpyAsync(frames_of(h, sector, elevation), s.d_frames, sizeof(unsigned) * 2 * (1 + c.m / 2), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(h, hipEventRecord(s.done, s.stream));
     s.busy = true;
     s.loaded = true;
@@ -861,7 +871,20 @@ int wrp_wait(wrp_handle h, int slot)
     if (!h || slot < 0 || slot >= (int)h->slots.size()) return WRP_ERR_INVALID;
     Slot &s = h->slots[slot];
     if (!s.busy) return WRP_ERR_STATE;
-    HIP_TRY(h, hipEventSynchronize(s.done));
+    // A slot's chain takes ~0.1 - 0.2 ms: the caller (one feeder thread per GPU, rpv2.cu:665-683) first LOOKS for that long
+    // -- hipEventSynchronize puts the thread to sleep, and the wake-up of a sleeping thread costs the cascade more than the
+    // sector's transfer takes (profiles/r05/feeder_breakdown.log) -- and only then blocks.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(s.done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(h, q);
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(WRP_WAIT_SPIN_US)) {
+            HIP_TRY(h, hipEventSynchronize(s.done));
+            break;
+        }
+    }
     s.busy = false;
     return WRP_OK;
 }
