@@ -127,3 +127,14 @@ def test_wire_drop_vh_is_the_12_byte_sample_without_bytes_8_to_11(host):
             host.wrph_wire_drop_vh(dst.ctypes.data, src.ctypes.data, samples, threads, portable)
             assert np.array_equal(dst[:samples * 8], want), (samples, threads, portable)
             assert (dst[samples * 8:] == 0xA5).all(), (samples, threads, portable)      # nothing written behind the last sample
+
+
+def test_fill_pool_survives_thousands_of_jobs_and_naps(host):
+    """The feeder's copy pool (host/wire.h: helpers that spin between sectors and sleep when none comes): 3000 sectors through
+    one pool of 4 threads, plain and VH-dropping copies alternating, with pauses long enough for the helpers to fall asleep
+    -- every output equal to the single-threaded copy."""
+    host.wrph_fill_pool_stress.argtypes = [C.c_int, C.c_long, C.c_size_t, C.c_int]
+    host.wrph_fill_pool_stress.restype = C.c_long
+    assert host.wrph_fill_pool_stress(4, 3000, 4096 + 7, 300) == 0
+    assert host.wrph_fill_pool_stress(3, 500, 1024 * 64, 0) == 0
+    assert host.wrph_fill_pool_stress(1, 50, 1000, 0) == 0

@@ -49,6 +49,28 @@ void wrph_wire_drop_vh(unsigned char *dst8, const unsigned char *src12, size_t s
     FillPool pool(threads);
     for (int rep = 0; rep < 3; rep++) pool.drop_vh((char *)dst8, (const char *)src12, samples);     // (the pool is reused per sector)
 }
+// FillPool under load: `jobs` sectors of `samples` samples through ONE pool of `threads` threads, alternating the VH-dropping
+// copy and the plain copy, a pause of `pause_us` every 64 jobs (so that the helpers fall asleep and are woken again);
+// returns the number of jobs whose output differed from the single-threaded copy
+long wrph_fill_pool_stress(int threads, long jobs, size_t samples, int pause_us)
+{
+    std::vector<unsigned char> src(samples * 12 + 64), want8(samples * 8), got(samples * 12 + 64);
+    FillPool pool(threads);
+    long bad = 0;
+    for (long j = 0; j < jobs; j++) {
+        for (size_t k = 0; k < src.size(); k += 97) src[k] = (unsigned char)(j * 31 + k);     // a few bytes change per job
+        if (j & 1) {
+            pool.copy((char *)got.data(), (const char *)src.data(), samples * 12);
+            bad += memcmp(got.data(), src.data(), samples * 12) != 0;
+        } else {
+            wire_drop_vh_portable(want8.data(), src.data(), samples);
+            pool.drop_vh((char *)got.data(), (const char *)src.data(), samples);
+            bad += memcmp(got.data(), want8.data(), samples * 8) != 0;
+        }
+        if (pause_us > 0 && (j & 63) == 63) std::this_thread::sleep_for(std::chrono::microseconds(pause_us));
+    }
+    return bad;
+}
 void wrph_aftoab(float *af, size_t n, unsigned char *ab) { aftoab(af, n, ab); }
 void wrph_abtoaf(unsigned char *ab, size_t n, float *af) { abtoaf(ab, n, af); }
 int wrph_dim3_at_depth(int w, int h, int d, int x, int y, int depth) { return Dimension3(w, h, d).at_depth(x, y, depth); }
