@@ -68,14 +68,9 @@ __device__ __forceinline__ void rb_derive_twiddles(cf (&tw)[16])
 // was written back: WRITE_SIZE 1.75 MB per sector, profiles/r03/fused_b_input_policy.log).
 constexpr int FUSED_B_INPUT_AUX = AUX_NT;
 // the row waves touch the slow lines (wrp_fused.h: fused_touch_slow_lines) of the input of the task this many tasks ahead
-// (the tile members request a task's input during the task before it), behind their hand-over of this half; 0 = never
-#ifndef WRP_FUSED_B_TOUCH_AHEAD
-#define WRP_FUSED_B_TOUCH_AHEAD 2
-#endif
-#ifndef WRP_FUSED_B_TOUCH_HALF
-#define WRP_FUSED_B_TOUCH_HALF 0
-#endif
-constexpr int FUSED_B_TOUCH_AHEAD = WRP_FUSED_B_TOUCH_AHEAD, FUSED_B_TOUCH_HALF = WRP_FUSED_B_TOUCH_HALF;
+// (the tile members request a task's input during the task before it), behind their hand-over of this half; 0 = never.
+// Measured (profiles/r05/ab_b_slow_line_touch.log): 2 / half 0 -14.2 %, 2 / half 1 -12.6 %, 3 -12.5 %, 1 +6.6 %
+constexpr int FUSED_B_TOUCH_AHEAD = 2, FUSED_B_TOUCH_HALF = 0;
 // Request pacing (wrp_fused.h): 16 = one load at a time over the task, 1.69 us/sector, HBM traffic 1.13 x the algorithmic
 // bytes; 4 = four quarters, 1.74 us/sector, 1.06 x (the smoother stream leaves fewer non-temporal lines per L2 set to evict
 // in place of the slot's): profiles/r03/fused_b_input_policy.log, ab_request_pacing_B.log.
@@ -381,10 +376,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             float2 *tee_task = TEE && tee ? tee + ((size_t)(trank + q * teams) * channels + ch) * (RB_M / 2) * RB_N : nullptr;
             fused_b_store(mid, ch, col_base, o, tee_task, 0);
             __builtin_amdgcn_sched_barrier(0);  // the loads below stay BEHIND the stores: the counted wait tells them apart
-            WRP_LB(5); WRP_LB(13); WRP_LB(2); WRP_LB(10);
+            // four requests behind the stores; with 12-byte samples (a member's pieces straddle lines) two, and two more behind
+            // A3: -2.8 % there, nothing for the other forms (profiles/r05/ab_b_after_touch_variants.log)
+            WRP_LB(5); WRP_LB(13);
+            if (RAW != 12) { WRP_LB(2); WRP_LB(10); }
             fused_b_group1_to_lds(smem, ga, gc);
             stamp(q, 2);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the 4 requests just issued: the stores are in the L2
+            // all but the requests just issued: the stores are in the L2
+            if (RAW != 12) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             stamp(q, 6);
             int last = 0;
             if (l == 0) last = atomicAdd(s_arrived + 1, 1) == 8 * q + 7;
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) __attribute__((amdgpu_waves_per_e
             __syncthreads();                    // A3: group 1 is in the image
             stamp(q, 3);
             WRP_LB(6);
+            if (RAW == 12) { WRP_LB(2); WRP_LB(10); }
             fused_b_stage2(smem);      // (its sixteen points + fifteen twiddles need registers: most of the rest is requested behind it)
             WRP_LB(14); WRP_LB(3);
             fused_b_stage3(smem, o);
