@@ -36,9 +36,23 @@ __global__ __launch_bounds__(512) void k_rewrite(float *buf, const float *in, fl
     const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(mine, 0, chunk, 0x00020000);
     v4f acc = {0, 0, 0, 0};
     for (int r = 0; r < reps; r++) {
+        if (st_sel >= 4) {
+            // the 2048 x 128 launch's slot stores (round 5): a 128-byte line of the rewritten buffer gets its two 64-byte HALVES
+            // from two different workgroups, s_slot and s_slot ^ 1 (4: same XCD when MODE & 4), at whatever times they get there;
+            // 5: from the same workgroup, all first halves and then all second halves
+            const rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(buf) + (size_t)(s_slot & ~1u) * chunk, 0, 2 * chunk, 0x00020000);
+            for (int pass = 0; pass < (st_sel == 5 ? 2 : 1); pass++) {
+                const int half = st_sel == 5 ? pass : (int)(s_slot & 1);
+                const int first = st_sel == 5 ? (int)(s_slot & 1) * (chunk / 128) : 0, lines = st_sel == 5 ? chunk / 128 : 2 * chunk / 128;
+                for (int line = tid >> 2; line < lines; line += 128) {
+                    v4f v = {(float)r, (float)line, 1.f, 2.f};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rp, (first + line) * 128 + half * 64 + (tid & 3) * 16, 0, 0);
+                }
+            }
+        } else
         for (int off = tid * 16; off < chunk; off += 512 * 16) {
             v4f v = {(float)r, (float)off, 1.f, 2.f};
-            // cache policy of the rewritten buffer's stores: 0 plain, 1 nt, 2 sc0
+            // cache policy of the rewritten buffer's stores: 0 plain, 1 nt, 2 sc0 (3: b64 pairs; 4, 5: half lines, above)
             if (st_sel == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 0);
             else if (st_sel == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 2);
             else if (st_sel == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rb, off, 0, 1);
