@@ -367,6 +367,7 @@ def main():
         "avg_launch_us": round(ms_total * 1e3 / (iters * launches), 2),
         "valu_busy": busy and busy.get("valu_busy"), "lds_busy": busy and busy.get("lds_busy"),
         "no_input_us_per_sector": floor and floor.get("no_input_us_per_sector"),
+        "l2_hit_input_us_per_sector": floor and floor.get("l2_hit_input_us_per_sector"),
     }
     if not fused:
         roofline["range_pass_us_per_sector"] = round(ms_range * 1e3 / (iters * S), 3)
