@@ -23,6 +23,12 @@ if [ "${1:-}" = build ]; then
          -e 's/buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 \* r \* DP_N \* 8)/buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * (r \& 1) * DP_N * 8)/' \
          -e 's/auto tile_src = \[&\](int q) { return iq + ((size_t)(trank + (q >> 1) \* teams) \* channels + (q & 1)) \* RP_M \* (size_t)n; };/auto tile_src = [\&](int q) { return iq + 0 * q; };/' $L/hit/pkg/csrc/wrp_fused.h
   grep -c "(R & 1)\|(r & 1) \* DP_N\|iq + 0 \* q" $L/hit/pkg/csrc/wrp_fused.h
+  # the same for the 2048 x 128 launch: rows p0 + 128 (r & 1) of sector 0 (256 KiB per channel), the touches as well
+  sed -i -e 's/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 \* R \* row_stride)/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * (R \& 1) * row_stride)/' \
+         -e 's/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 \* r \* row_stride)/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * (r \& 1) * row_stride)/' \
+         -e 's/return iq + ((size_t)(trank + q \* teams) \* channels + ch) \* RB_M \* (size_t)RB_N;/return iq + (size_t)ch * RB_M * (size_t)RB_N;/' \
+         -e 's/(size_t)(trank + (q >= 0 \&\& q < tasks ? q : 0) \* teams) \* (RAW/(size_t)0 * (RAW/' $L/hit/pkg/csrc/wrp_fused_b.h
+  grep -c "(R & 1) \* row_stride\|(r & 1) \* row_stride\|iq + (size_t)ch \* RB_M\|(size_t)0 \* (RAW" $L/hit/pkg/csrc/wrp_fused_b.h
   /opt/rocm/bin/hipcc $FLAGS -shared -o $L/libwrp_l2hit.so $L/hit/pkg/csrc/wrp_engine.hip
   cp $ROOT/weather-radar-processing_amd/lib/libwrp.so $L/libwrp_product.so
   ls -la $L/*.so
@@ -30,7 +36,7 @@ else
   R=${2:-r05}; OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
   cd $ROOT
   python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so $L/libwrp_l2hit.so --rounds 20 --no-check > $OUT/floor_A.log 2>&1
-  python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so --rounds 20 --no-check --shape B > $OUT/floor_B.log 2>&1
+  python3 tools/ab.py $L/libwrp_product.so $L/libwrp_noinput.so $L/libwrp_l2hit.so --rounds 20 --no-check --shape B > $OUT/floor_B.log 2>&1
   python3 - $OUT <<'PY'
 import json, re, sys, os
 sys.path.insert(0, os.getcwd())
