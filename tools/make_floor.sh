@@ -12,7 +12,7 @@ if [ "${1:-}" = build ]; then
   cp $ROOT/include/wrp.h $L/include/; cp $ROOT/weather-radar-processing_amd/csrc/* $L/pkg/csrc/
   # every descriptor of the INPUT (tile loads of both launches and both formats, the row waves' touches): never valid
   sed -i -E '/make_rsrc\((src|sector_raw|range), valid \?/s/valid \?/false \&\& valid ?/' $L/pkg/csrc/wrp_fused.h $L/pkg/csrc/wrp_fused_b.h
-  grep -c "false && valid" $L/pkg/csrc/wrp_fused.h $L/pkg/csrc/wrp_fused_b.h
+  [ "$(cat $L/pkg/csrc/wrp_fused.h $L/pkg/csrc/wrp_fused_b.h | grep -c "false && valid")" = 6 ] || { echo "make_floor.sh: the no-input edits no longer match the sources"; exit 1; }
   FLAGS=$(grep '^HIPFLAGS' $ROOT/Makefile | sed 's/.*?= //; s/\$(ARCH)/gfx950/')
   /opt/rocm/bin/hipcc $FLAGS -shared -o $L/libwrp_noinput.so $L/pkg/csrc/wrp_engine.hip
   # ... and the 1024 x 512 launch with its input SERVED BY THE L2: the same sixteen requests per lane and task, but every task reads
@@ -22,13 +22,13 @@ if [ "${1:-}" = build ]; then
   sed -i -e 's/buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 \* R \* DP_N \* 8)/buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * (R \& 1) * DP_N * 8)/' \
          -e 's/buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 \* r \* DP_N \* 8)/buf_load_f4<FUSED_INPUT_AUX>(rs, voff, 64 * (r \& 1) * DP_N * 8)/' \
          -e 's/auto tile_src = \[&\](int q) { return iq + ((size_t)(trank + (q >> 1) \* teams) \* channels + (q & 1)) \* RP_M \* (size_t)n; };/auto tile_src = [\&](int q) { return iq + 0 * q; };/' $L/hit/pkg/csrc/wrp_fused.h
-  grep -c "(R & 1)\|(r & 1) \* DP_N\|iq + 0 \* q" $L/hit/pkg/csrc/wrp_fused.h
+  [ "$(grep -c "(R & 1)\|(r & 1) \* DP_N\|iq + 0 \* q" $L/hit/pkg/csrc/wrp_fused.h)" = 3 ] || { echo "make_floor.sh: the L2-hit edits of wrp_fused.h no longer match the sources"; exit 1; }
   # the same for the 2048 x 128 launch: rows p0 + 128 (r & 1) of sector 0 (256 KiB per channel), the touches as well
   sed -i -e 's/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 \* R \* row_stride)/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * (R \& 1) * row_stride)/' \
          -e 's/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 \* r \* row_stride)/buf_load_f4<FUSED_B_INPUT_AUX>(rs, voff, 128 * (r \& 1) * row_stride)/' \
          -e 's/return iq + ((size_t)(trank + q \* teams) \* channels + ch) \* RB_M \* (size_t)RB_N;/return iq + (size_t)ch * RB_M * (size_t)RB_N;/' \
          -e 's/(size_t)(trank + (q >= 0 \&\& q < tasks ? q : 0) \* teams) \* (RAW/(size_t)0 * (RAW/' $L/hit/pkg/csrc/wrp_fused_b.h
-  grep -c "(R & 1) \* row_stride\|(r & 1) \* row_stride\|iq + (size_t)ch \* RB_M\|(size_t)0 \* (RAW" $L/hit/pkg/csrc/wrp_fused_b.h
+  [ "$(grep -c "(R & 1) \* row_stride\|(r & 1) \* row_stride\|iq + (size_t)ch \* RB_M\|(size_t)0 \* (RAW" $L/hit/pkg/csrc/wrp_fused_b.h)" = 4 ] || { echo "make_floor.sh: the L2-hit edits of wrp_fused_b.h no longer match the sources"; exit 1; }
   /opt/rocm/bin/hipcc $FLAGS -shared -o $L/libwrp_l2hit.so $L/hit/pkg/csrc/wrp_engine.hip
   cp $ROOT/weather-radar-processing_amd/lib/libwrp.so $L/libwrp_product.so
   ls -la $L/*.so
